@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def golden_names():
+    g = os.path.join(ROOT, "tests", "golden")
+    return sorted(f[:-4] for f in os.listdir(g) if f.endswith(".npz"))
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import cafe_oracle
+    cafe_oracle.build()
+    return cafe_oracle
