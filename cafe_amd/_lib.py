@@ -1,0 +1,78 @@
+"""ctypes binding of libcafe_hip.so (include/cafe_hip.h).  Fails loudly if the library is missing:
+there is no CPU fallback behind these calls."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcafe_hip.so")
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_f32p = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+
+# every symbol include/cafe_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "cafe_last_error": (ctypes.c_char_p, []),
+    "cafe_version": (ctypes.c_int, []),
+    "init": (None, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
+    "batch_query": (_i32p, [_u32p, ctypes.c_int]),
+    "batch_insert": (_i32p, [_u32p, ctypes.c_int]),
+    "batch_insert_val": (_i32p, [_u32p, _f32p, ctypes.c_int]),
+    "analyse": (ctypes.c_double, [_u32p, ctypes.c_int]),
+    "analyse1": (ctypes.c_double, [_u32p, ctypes.c_int]),
+    "update": (None, []),
+    "save_state": (ctypes.c_int, [ctypes.c_char_p]),
+    "load_state": (ctypes.c_int, [ctypes.c_char_p]),
+    "cafe_global_sketch": (_vp, []),
+    "cafe_sketch_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]),
+    "cafe_sketch_destroy": (ctypes.c_int, [_vp]),
+    "cafe_sketch_dims": (ctypes.c_int, [_vp, _i32p]),
+    "cafe_sketch_scalars": (ctypes.c_int, [_vp, _f32p, _i32p, ctypes.POINTER(ctypes.c_double)]),
+    "cafe_sketch_export": (ctypes.c_int, [_vp, _i32p, _f32p, _i32p, _u8p, _i32p, _f32p, _i32p, _i32p, _u8p, _u32p]),
+    "cafe_sketch_import": (ctypes.c_int, [_vp, _i32p, _f32p, _i32p, _u8p, _i32p, _f32p, _i32p, _i32p, _u8p, _u32p,
+                                          ctypes.c_int, ctypes.c_float, _i32p, ctypes.c_double]),
+    "cafe_sketch_save": (ctypes.c_int, [_vp, ctypes.c_char_p]),
+    "cafe_sketch_load": (ctypes.c_int, [_vp, ctypes.c_char_p]),
+    "cafe_sketch_rebuild_free_list": (ctypes.c_int, [_vp, _vp]),
+    "cafe_sketch_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
+    "cafe_sketch_counters": (ctypes.c_int, [_vp, _i64p]),
+    "cafe_query_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "cafe_insert_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
+    "cafe_tables_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp,
+                                          ctypes.POINTER(_vp), _i64p, _i32p]),
+    "cafe_tables_destroy": (ctypes.c_int, [_vp]),
+    "cafe_forward_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "cafe_scores_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "cafe_migrate_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
+    "cafe_backward_sgd_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_float, _vp]),
+}
+
+_LIB = None
+
+
+class CafeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcafe_hip.so and bind every declared symbol.  Raises if the library was not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise CafeError(f"{LIB_PATH} not found: build it with `make -C cafe_amd/csrc` "
+                            "(or __graft_entry__.build()); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)           # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise CafeError(f"{what}: {load().cafe_last_error().decode(errors='replace')}")

@@ -1,0 +1,338 @@
+// cafe_embed.hip -- the tensor half of CAFE's embedding layer on MI355X: fused sketch query + hot/cold
+// routed row gather (forward), importance scores from the output gradient, cold->hot row migration, and
+// the sparse backward + SGD update.  Behaviour follows tricks/sk_embedding_bag.py (cited per kernel).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "cafe_internal.h"
+
+using namespace cafe;
+
+// ------------------------------------------------------------------------------------------------
+// tables descriptor
+// ------------------------------------------------------------------------------------------------
+extern "C" int cafe_tables_create(cafe_tables_t **out, int num_fields, int dim, int hotn, float *d_w_hot,
+                                  float *const *d_w_cold, const int64_t *id_offset, const int32_t *hash_size) {
+    if (!out || num_fields <= 0 || dim <= 0 || (dim & 3) || dim > 1024 || hotn <= 0) {
+        set_error("cafe_tables_create: need num_fields > 0, hotn > 0 and dim a multiple of 4 up to 1024 (got %d, %d, %d)",
+                  num_fields, hotn, dim);
+        return 1;
+    }
+    cafe_tables *t = new cafe_tables();
+    t->num_fields = num_fields; t->dim = dim; t->hotn = hotn; t->d_w_hot = d_w_hot;
+    std::vector<int64_t> base(num_fields + 1, 0);
+    for (int f = 0; f < num_fields; ++f) {
+        if (hash_size[f] <= 0) { set_error("cafe_tables_create: hash_size[%d] = %d", f, hash_size[f]); delete t; return 1; }
+        base[f + 1] = base[f] + hash_size[f];
+    }
+    t->total_cold_rows = base[num_fields];
+    CAFE_HIP_CHECK(hipMalloc(&t->d_w_cold, sizeof(float *) * num_fields));
+    CAFE_HIP_CHECK(hipMalloc(&t->d_id_offset, 8 * num_fields));
+    CAFE_HIP_CHECK(hipMalloc(&t->d_hash_size, 4 * num_fields));
+    CAFE_HIP_CHECK(hipMalloc(&t->d_cold_base, 8 * (num_fields + 1)));
+    CAFE_HIP_CHECK(hipMemcpy(t->d_w_cold, d_w_cold, sizeof(float *) * num_fields, hipMemcpyHostToDevice));
+    CAFE_HIP_CHECK(hipMemcpy(t->d_id_offset, id_offset, 8 * num_fields, hipMemcpyHostToDevice));
+    CAFE_HIP_CHECK(hipMemcpy(t->d_hash_size, hash_size, 4 * num_fields, hipMemcpyHostToDevice));
+    CAFE_HIP_CHECK(hipMemcpy(t->d_cold_base, base.data(), 8 * (num_fields + 1), hipMemcpyHostToDevice));
+    *out = t;
+    return 0;
+}
+
+extern "C" int cafe_tables_destroy(cafe_tables_t *t) {
+    if (!t) return 0;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(t->d_w_cold); (void)hipFree(t->d_id_offset); (void)hipFree(t->d_hash_size); (void)hipFree(t->d_cold_base);
+    t->ws_norm.release(); t->ws_bwd_a.release(); t->ws_bwd_b.release(); t->ws_bwd_c.release(); t->ws_bwd_d.release();
+    t->ws_misc.release();
+    delete t;
+    return 0;
+}
+
+static inline int lanes_per_row(int dim) {
+    int v = dim / 4, l = 1;
+    while (l < v) l <<= 1;
+    return l > 64 ? 64 : l;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: sk_embedding_bag.py:101-113 (query) + 119-152 (two embedding_bag + where), fused.
+// LPG lanes cooperate on one lookup: every lane probes the same 32-B val|dic half bucket (one request
+// per group), then the group copies the selected row as float4 per lane (coalesced 16 B/lane).
+// ------------------------------------------------------------------------------------------------
+template <int LPG>
+__global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ mt, FastMod fm1,
+                                                 const float *__restrict__ w_hot, float *const *__restrict__ w_cold,
+                                                 const int64_t *__restrict__ id_offset, const int32_t *__restrict__ hash_size,
+                                                 const int64_t *__restrict__ local_ids, int batch, int total, int dim,
+                                                 int32_t *__restrict__ gids, int32_t *__restrict__ que,
+                                                 float *__restrict__ out) {
+    const int lig = threadIdx.x % LPG;
+    const int groups = (gridDim.x * blockDim.x) / LPG;
+    const int dim4 = dim >> 2;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) / LPG; i < total; i += groups) {
+        const int f = i / batch;
+        const int32_t g = (int32_t)(local_ids[i] + id_offset[f]);      // sk_embedding_bag.py:103
+        const uint32_t x = (uint32_t)g;
+        const int4 *p = reinterpret_cast<const int4 *>(&mt[fast_hash(x, fm1)]);
+        const int4 v = p[0], d = p[1];
+        const int32_t val[4] = {v.x, v.y, v.z, v.w}, dic[4] = {d.x, d.y, d.z, d.w};
+        const int32_t q = query_bucket(val, dic, x);
+        // hot: W_h[|q| % hotn] = W_h[slot]; cold: W_hash[|q| % hash_size] (sk_embedding_bag.py:134-150)
+        const float *row = q < 0 ? w_hot + (size_t)(-q) * dim
+                                 : w_cold[f] + (size_t)((uint32_t)q % (uint32_t)hash_size[f]) * dim;
+        if (lig == 0) { gids[i] = g; que[i] = q; }
+        float4 *o = reinterpret_cast<float4 *>(out + (size_t)i * dim);
+        for (int c = lig; c < dim4; c += LPG) o[c] = reinterpret_cast<const float4 *>(row)[c];
+    }
+}
+
+extern "C" int cafe_forward_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, int batch,
+                                int32_t *d_gids, int32_t *d_que, float *d_out, cafe_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const long total_l = (long)t->num_fields * batch;
+    if (batch <= 0 || total_l > 0x7fffffffL / 4) { set_error("cafe_forward_dev: bad batch %d", batch); return 1; }
+    const int total = (int)total_l;
+    const int lpg = lanes_per_row(t->dim);
+    const long threads = (long)total * lpg;
+    const int blocks = (int)std::min<long>((threads + 255) / 256, 256 * 16);
+    FastMod fm1 = make_fastmod(s->n1);
+#define CAFE_FWD(L)                                                                                              \
+    hipLaunchKernelGGL(k_forward<L>, dim3(blocks), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold,     \
+                       t->d_id_offset, t->d_hash_size, d_local_ids, batch, total, t->dim, d_gids, d_que, d_out)
+    switch (lpg) {
+        case 1: CAFE_FWD(1); break;
+        case 2: CAFE_FWD(2); break;
+        case 4: CAFE_FWD(4); break;
+        case 8: CAFE_FWD(8); break;
+        case 16: CAFE_FWD(16); break;
+        case 32: CAFE_FWD(32); break;
+        default: CAFE_FWD(64); break;
+    }
+#undef CAFE_FWD
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scores: sk_embedding_bag.py:178-189, intended semantics: the L2 norm of each lookup's own
+// output-gradient row, scaled per field so that scores average 1.  Two deterministic passes.
+// ------------------------------------------------------------------------------------------------
+template <int LPG>
+__global__ void __launch_bounds__(256) k_grad_norm(const float *__restrict__ g, int total, int dim, float *__restrict__ gn) {
+    const int lig = threadIdx.x % LPG;
+    const int groups = (gridDim.x * blockDim.x) / LPG;
+    const int dim4 = dim >> 2;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) / LPG; i < total; i += groups) {
+        const float4 *r = reinterpret_cast<const float4 *>(g + (size_t)i * dim);
+        float acc = 0.f;
+        for (int c = lig; c < dim4; c += LPG) {
+            float4 v = r[c];
+            acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
+        }
+#pragma unroll
+        for (int o = LPG >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, LPG);
+        if (lig == 0) gn[i] = sqrtf(acc);
+    }
+}
+
+// one workgroup per field: fixed-order sum of the field's norms, then s_i = gn_i * batch / sum
+__global__ void __launch_bounds__(1024) k_field_scale(const float *__restrict__ gn, int batch, float *__restrict__ scores) {
+    __shared__ float part[1024];
+    const int f = blockIdx.x;
+    const float *src = gn + (size_t)f * batch;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < batch; i += blockDim.x) acc += src[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float sum = part[0];
+    const float nb = (float)batch;
+    float *dst = scores + (size_t)f * batch;
+    for (int i = threadIdx.x; i < batch; i += blockDim.x) dst[i] = src[i] * nb / sum;
+}
+
+extern "C" int cafe_scores_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_scores, cafe_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int total = t->num_fields * batch;
+    if (t->ws_norm.reserve((size_t)total * 4 + 16)) return 1;
+    float *gn = t->ws_norm.as<float>();
+    const int lpg = lanes_per_row(t->dim);
+    const long threads = (long)total * lpg;
+    const int blocks = (int)std::min<long>((threads + 255) / 256, 256 * 16);
+#define CAFE_GN(L) hipLaunchKernelGGL(k_grad_norm<L>, dim3(blocks), dim3(256), 0, st, d_grad_out, total, t->dim, gn)
+    switch (lpg) {
+        case 1: CAFE_GN(1); break;
+        case 2: CAFE_GN(2); break;
+        case 4: CAFE_GN(4); break;
+        case 8: CAFE_GN(8); break;
+        case 16: CAFE_GN(16); break;
+        case 32: CAFE_GN(32); break;
+        default: CAFE_GN(64); break;
+    }
+#undef CAFE_GN
+    hipLaunchKernelGGL(k_field_scale, dim3(t->num_fields), dim3(1024), 0, st, gn, batch, d_scores);
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// migration: sk_embedding_bag.py:199-208.  Newly hot ids are few, so one lane checks each lookup and
+// copies the row itself.  Only ids that the sketch now reports hot are copied (SURVEY Q3 fence).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_migrate(const MainBucket *__restrict__ mt, FastMod fm1, float *__restrict__ w_hot,
+                          float *const *__restrict__ w_cold, const int32_t *__restrict__ hash_size,
+                          const int64_t *__restrict__ local_ids, const int32_t *__restrict__ gids,
+                          const int32_t *__restrict__ ins, int batch, int total, int dim) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total || !ins[i]) return;
+    const uint32_t x = (uint32_t)gids[i];
+    const MainBucket &b = mt[fast_hash(x, fm1)];
+    const int32_t q = query_bucket(b.val, b.dic, x);        // the re-query of sk_embedding_bag.py:201-204
+    if (q >= 0) return;
+    const int f = i / batch;
+    const int64_t src_row = local_ids[i] % (int64_t)hash_size[f];     // LOCAL id: sk_embedding_bag.py:207
+    const float4 *src = reinterpret_cast<const float4 *>(w_cold[f] + (size_t)src_row * dim);
+    float4 *dst = reinterpret_cast<float4 *>(w_hot + (size_t)(-q) * dim);
+    for (int c = 0; c < (dim >> 2); ++c) dst[c] = src[c];
+}
+
+extern "C" int cafe_migrate_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
+                                const int32_t *d_ins, int batch, cafe_stream_t stream) {
+    const int total = t->num_fields * batch;
+    hipLaunchKernelGGL(k_migrate, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_main,
+                       make_fastmod(s->n1), t->d_w_hot, t->d_w_cold, t->d_hash_size, d_local_ids, d_gids, d_ins, batch,
+                       total, t->dim);
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward + SGD: the autograd backward of the forward routes each output-gradient row to the table row
+// it was read from; torch.optim.SGD then does W -= lr * (sum of the rows' gradients)
+// (dlrm_s_pytorch.py:1658).  Here: unified row keys -> sort -> segment sums -> one read-modify-write per
+// touched row.  Segments that cross a chunk border finish with float atomics.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_row_keys(const int32_t *__restrict__ gids, const int32_t *__restrict__ que,
+                           const int32_t *__restrict__ hash_size, const int64_t *__restrict__ cold_base, int hotn,
+                           int batch, int total, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int32_t q = que[i];
+    uint32_t k;
+    if (q < 0) {
+        k = (uint32_t)(-q) % (uint32_t)hotn;
+    } else {
+        const int f = i / batch;
+        k = (uint32_t)hotn + (uint32_t)cold_base[f] + (uint32_t)q % (uint32_t)hash_size[f];
+    }
+    (void)gids;
+    keys[i] = k;
+    vals[i] = (uint32_t)i;
+}
+
+template <int LPG, int CHUNK>
+__global__ void __launch_bounds__(256) k_segment_sgd(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                     const float *__restrict__ grad, float *__restrict__ w_hot,
+                                                     float *const *__restrict__ w_cold, const int64_t *__restrict__ cold_base,
+                                                     int hotn, int batch, int total, int dim, float lr) {
+    static_assert(LPG <= 64, "group within a wave");
+    const int lig = threadIdx.x % LPG;
+    const int chunk = (blockIdx.x * blockDim.x + threadIdx.x) / LPG;
+    const int begin = chunk * CHUNK;
+    if (begin >= total) return;
+    const int end = min(begin + CHUNK, total);
+    const int dim4 = dim >> 2;
+    constexpr int MAXV = 4;               // float4 per lane: dim <= LPG*4*MAXV (host checks)
+    float4 acc[MAXV];
+    int s = begin;
+    while (s < end) {
+        const uint32_t key = keys[s];
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int e = s;
+        while (e < end && keys[e] == key) {
+            const float4 *g = reinterpret_cast<const float4 *>(grad + (size_t)vals[e] * dim);
+#pragma unroll
+            for (int v = 0; v < MAXV; ++v) {
+                int c = lig + v * LPG;
+                if (c < dim4) { float4 x = g[c]; acc[v].x += x.x; acc[v].y += x.y; acc[v].z += x.z; acc[v].w += x.w; }
+            }
+            ++e;
+        }
+        // does the segment continue outside this chunk?
+        const bool open = (s == begin && begin > 0 && keys[begin - 1] == key) || (e == end && end < total && keys[end] == key);
+        float *row;
+        if (key < (uint32_t)hotn) {
+            row = w_hot + (size_t)key * dim;
+        } else {
+            const int f = (int)(vals[s] / (uint32_t)batch);
+            row = w_cold[f] + (size_t)((int64_t)(key - (uint32_t)hotn) - cold_base[f]) * dim;
+        }
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+            int c = lig + v * LPG;
+            if (c < dim4) {
+                if (open) {
+                    float *r = row + c * 4;
+                    atomicAdd(r + 0, -lr * acc[v].x); atomicAdd(r + 1, -lr * acc[v].y);
+                    atomicAdd(r + 2, -lr * acc[v].z); atomicAdd(r + 3, -lr * acc[v].w);
+                } else {
+                    float4 *r = reinterpret_cast<float4 *>(row) + c;
+                    float4 w = *r;
+                    w.x -= lr * acc[v].x; w.y -= lr * acc[v].y; w.z -= lr * acc[v].z; w.w -= lr * acc[v].w;
+                    *r = w;
+                }
+            }
+        }
+        s = e;
+    }
+}
+
+extern "C" int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_que,
+                                     const float *d_grad_out, int batch, float lr, cafe_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int total = t->num_fields * batch;
+    const int64_t rows = (int64_t)t->hotn + t->total_cold_rows;
+    if (rows >= (int64_t)0xFFFFFFFFLL) { set_error("cafe_backward_sgd_dev: more than 2^32 table rows"); return 1; }
+    if (t->ws_bwd_a.reserve((size_t)total * 4) || t->ws_bwd_b.reserve((size_t)total * 4) ||
+        t->ws_bwd_c.reserve((size_t)total * 4) || t->ws_bwd_d.reserve((size_t)total * 4)) return 1;
+    uint32_t *k0 = t->ws_bwd_a.as<uint32_t>(), *v0 = t->ws_bwd_b.as<uint32_t>();
+    uint32_t *k1 = t->ws_bwd_c.as<uint32_t>(), *v1 = t->ws_bwd_d.as<uint32_t>();
+    hipLaunchKernelGGL(k_row_keys, dim3((total + 255) / 256), dim3(256), 0, st, d_gids, d_que, t->d_hash_size,
+                       t->d_cold_base, t->hotn, batch, total, k0, v0);
+    int bits = 1;
+    while (bits < 32 && ((int64_t)1 << bits) < rows) ++bits;
+    size_t tmp = 0;
+    CAFE_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp, k0, k1, v0, v1, (size_t)total, 0, bits, st));
+    if (t->ws_misc.reserve(tmp + 256)) return 1;
+    CAFE_HIP_CHECK(rocprim::radix_sort_pairs(t->ws_misc.p, tmp, k0, k1, v0, v1, (size_t)total, 0, bits, st));
+    const int lpg = lanes_per_row(t->dim);
+    if (t->dim > lpg * 16) { set_error("cafe_backward_sgd_dev: dim %d too large", t->dim); return 1; }
+    constexpr int CH = 16;
+    const int chunks = (total + CH - 1) / CH;
+    const long threads = (long)chunks * lpg;
+    const int blocks = (int)((threads + 255) / 256);
+#define CAFE_SEG(L)                                                                                               \
+    hipLaunchKernelGGL((k_segment_sgd<L, CH>), dim3(blocks), dim3(256), 0, st, k1, v1, d_grad_out, t->d_w_hot,     \
+                       t->d_w_cold, t->d_cold_base, t->hotn, batch, total, t->dim, lr)
+    switch (lpg) {
+        case 1: CAFE_SEG(1); break;
+        case 2: CAFE_SEG(2); break;
+        case 4: CAFE_SEG(4); break;
+        case 8: CAFE_SEG(8); break;
+        case 16: CAFE_SEG(16); break;
+        case 32: CAFE_SEG(32); break;
+        default: CAFE_SEG(64); break;
+    }
+#undef CAFE_SEG
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,79 @@
+// cafe_internal.h -- host-side handle definitions shared by the translation units of libcafe_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/cafe_hip.h"
+#include "cafe_core.h"
+
+namespace cafe {
+
+void set_error(const char *fmt, ...);
+
+#define CAFE_HIP_CHECK(expr)                                                                         \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            cafe::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 1;                                                                                \
+        }                                                                                            \
+    } while (0)
+
+// Growable device buffer owned by a handle; grows outside of any kernel's lifetime only
+// (hipMalloc/hipFree synchronise, so callers size workspaces before launching).
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T *as() { return (T *)p; }
+};
+
+struct ParWorkspace;   // parallel insert workspace, cafe_insert_par.hip
+
+}  // namespace cafe
+
+struct cafe_sketch {
+    int device = 0;
+    int lim = 0, n1 = 0, n2 = 0, adjust = 1, lru_first = 1;
+    // host-tracked scalars: they depend on the number of calls only (sketch.cpp:282-289)
+    double alpha = 1.0, decay = 1.0;
+    int batch_num = 0, flip = 0;
+    // device state
+    cafe::MainBucket *d_main = nullptr;
+    cafe::LruBucket *d_lru = nullptr;
+    uint32_t *d_fifo = nullptr;
+    uint32_t fifo_cap = 1;
+    cafe::DevState *d_state = nullptr;
+    // upper bound of real_n known to the host without a sync (each inserted id raises real_n by at most 1)
+    long long real_n_ub = 0;
+    // options / counters
+    int opt_serial = 0, opt_max_rounds = 6;
+    int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // workspaces
+    cafe::DevBuf ws_reset_keys, ws_reset_keys2, ws_reset_tmp, ws_reset_flags, ws_misc;
+    cafe::ParWorkspace *par = nullptr;
+    int32_t *h_pinned = nullptr;    // small pinned readback area
+};
+
+struct cafe_tables {
+    int num_fields = 0, dim = 0, hotn = 0;
+    float *d_w_hot = nullptr;
+    float **d_w_cold = nullptr;      // device array [F] of device pointers
+    int64_t *d_id_offset = nullptr;  // device array [F]
+    int32_t *d_hash_size = nullptr;  // device array [F]
+    int64_t *d_cold_base = nullptr;  // device array [F+1]: first row of field f in the unified cold row space
+    int64_t total_cold_rows = 0;
+    cafe::DevBuf ws_norm, ws_bwd_a, ws_bwd_b, ws_bwd_c, ws_bwd_d, ws_misc;
+};
+
+namespace cafe {
+// cafe_insert_par.hip
+int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st);
+void par_free(cafe_sketch *s);
+// cafe_sketch.hip
+int launch_serial_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
+                         int only_if_fallback, hipStream_t st);
+}  // namespace cafe

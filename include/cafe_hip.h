@@ -1,0 +1,133 @@
+/*
+ * cafe_hip.h -- C ABI of libcafe_hip.so, the MI355X (gfx950) implementation of CAFE's sketch-driven
+ * compact embedding layer.  Plain pointers and sizes only; no torch types.
+ *
+ * Two groups of entry points:
+ *
+ *  (A) the reference's own sketch ABI (tricks/sketch.cpp:300-327), same names, same argument meaning,
+ *      host pointers in / pointer to library-owned result storage out.  A process that does
+ *      ctypes.CDLL("libcafe_hip.so") instead of the g++-built sklib.so (dlrm_s_pytorch.py:1402-1403)
+ *      gets the GPU sketch behind the calls it already makes.
+ *
+ *  (B) handle-based entry points on DEVICE pointers and a HIP stream, which is what the Python
+ *      module (cafe_amd/sk_embedding_bag.py, mirroring tricks/sk_embedding_bag.py) uses so that ids,
+ *      scores and embedding rows never leave HBM.
+ *
+ * All functions of group (B) return 0 on success, non-zero on error (text via cafe_last_error()).
+ * Nothing here falls back to the CPU: without a GPU every compute call fails.
+ */
+#ifndef CAFE_HIP_H
+#define CAFE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cafe_sketch cafe_sketch_t;   /* one HotSketch (the reference's global `ss`, sketch.cpp:297) */
+typedef struct cafe_tables cafe_tables_t;   /* hot table + per-field cold tables of one model replica/shard */
+typedef void *cafe_stream_t;                /* hipStream_t */
+
+const char *cafe_last_error(void);
+int cafe_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (A) reference-compatible ABI -- one process-global sketch on the current HIP device
+ * ---------------------------------------------------------------------------------------------- */
+
+/* sketch.cpp:309-313 `init`: (re)creates the global sketch.  Unlike the reference it also resets the
+ * decay counters, which the reference leaves as process globals (sketch.cpp:11-13). */
+void init(int n, int Threshold, int adjust_thres, double alp);
+/* sketch.cpp:300-302 / 260-265.  Returns library-owned storage, valid until the next batch_query. */
+int *batch_query(uint32_t *data, int len);
+/* sketch.cpp:303-305 / 266-280. */
+int *batch_insert(uint32_t *data, int len);
+/* sketch.cpp:306-308 / 281-296. */
+int *batch_insert_val(uint32_t *data, float *v, int len);
+/* sketch.cpp:314-320 and 321-327. */
+double analyse(uint32_t *data, int len);
+double analyse1(uint32_t *data, int len);
+/* Called by the reference driver on checkpoint load (dlrm_s_pytorch.py:1510-1511) but absent from
+ * tricks/sketch.cpp; semantics of ArtifactEvaluation/embeddings/sketch.cpp:61-75,219-222: rebuild the
+ * free list from the hot slots found in the tables. */
+void update(void);
+/* TOIS_revision/PinSAGE/sketch.cpp:333-402 counterparts (own file format). */
+int save_state(const char *path);
+int load_state(const char *path);
+/* The handle behind group (A), for callers that want to mix both groups. */
+cafe_sketch_t *cafe_global_sketch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (B) handle-based, device pointers
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Replaces lib.init (sketch.cpp:309-313, constructor 44-70) with an explicit handle on the current
+ * device.  lru_first: how reset() orders equal scores across the two tables; the reference orders by
+ * heap address (sketch.cpp:79,96), which at production sizes puts the LRU table first (1). */
+int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, int adjust_thres, double alpha, int lru_first);
+int cafe_sketch_destroy(cafe_sketch_t *s);
+
+/* out[0..3] = n1, n2, lim, free-list length (synchronises the device). */
+int cafe_sketch_dims(cafe_sketch_t *s, int32_t *out);
+/* thr, {num, real_n, clock, flip, batch_num, resets}, decay (synchronises). */
+int cafe_sketch_scalars(cafe_sketch_t *s, float *thr, int32_t *ints6, double *decay);
+/* Full state in the oracle's structure-of-arrays layout ([n1*4], [n1], [n2*4], [n2], free list in pop
+ * order); host pointers; synchronises.  Used by the parity tests and by save_state. */
+int cafe_sketch_export(cafe_sketch_t *s, int32_t *mval, float *mcnt, int32_t *mdic, uint8_t *mflip,
+                       int32_t *lval, float *lcnt, int32_t *ldic, int32_t *lt, uint8_t *lflip, uint32_t *fifo);
+int cafe_sketch_import(cafe_sketch_t *s, const int32_t *mval, const float *mcnt, const int32_t *mdic,
+                       const uint8_t *mflip, const int32_t *lval, const float *lcnt, const int32_t *ldic,
+                       const int32_t *lt, const uint8_t *lflip, const uint32_t *fifo, int fifo_len,
+                       float thr, const int32_t *ints6, double decay);
+int cafe_sketch_save(cafe_sketch_t *s, const char *path);
+int cafe_sketch_load(cafe_sketch_t *s, const char *path);
+/* Rebuild the free list from the tables (see `update` above). */
+int cafe_sketch_rebuild_free_list(cafe_sketch_t *s, cafe_stream_t stream);
+
+/* Options: "serial_insert" (1 = always use the one-lane in-order kernel), "max_rounds" (fix-point
+ * rounds of the parallel insert before it gives the batch to the in-order kernel). */
+int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int value);
+/* Counters since creation: [0] insert calls, [1] calls finished by the parallel path, [2] calls given
+ * to the in-order kernel, [3] fix-point rounds used in total, [4] resets, [5] largest round count. */
+int cafe_sketch_counters(cafe_sketch_t *s, int64_t *out8);
+
+/* sketch.cpp:260-265 batch_query: d_que[i] = -slot if d_ids[i] holds a hot slot, else d_ids[i]. */
+int cafe_query_dev(cafe_sketch_t *s, const int32_t *d_ids, int n, int32_t *d_que, cafe_stream_t stream);
+/* sketch.cpp:281-296 batch_insert_val (d_scores != NULL) / 266-280 batch_insert (NULL): exactly the
+ * state and d_ins[] that the reference's in-order loop produces for this batch. */
+int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
+                    cafe_stream_t stream);
+
+/* ---- tables: shared hot table (dlrm_s_pytorch.py:439-442) + per-field cold tables
+ *      (sk_embedding_bag.py:75-80).  Arrays are HOST arrays of length num_fields; they are copied. ---- */
+int cafe_tables_create(cafe_tables_t **out, int num_fields, int dim, int hotn, float *d_w_hot,
+                       float *const *d_w_cold, const int64_t *id_offset, const int32_t *hash_size);
+int cafe_tables_destroy(cafe_tables_t *t);
+
+/* sk_embedding_bag.py:101-113 (query) + 119-152 (forward), all fields in one launch.
+ * d_local_ids: [num_fields, batch] int64 per-field ids (the reference's lS_i, one index per bag);
+ * d_gids out:  [num_fields*batch] int32 = (int32)(id + id_offset[f]) (sk_embedding_bag.py:103);
+ * d_que out:   [num_fields*batch] int32, batch_query of d_gids;
+ * d_out:       [num_fields, batch, dim] float32 = hot ? W_hot[slot] : W_cold[f][gid % hash_size[f]]. */
+int cafe_forward_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, int batch,
+                     int32_t *d_gids, int32_t *d_que, float *d_out, cafe_stream_t stream);
+
+/* sk_embedding_bag.py:178-189 with the intended semantics: d_scores[f*batch+i] =
+ * ||g_i|| * batch / sum_j ||g_j|| over field f.  d_grad_out: [num_fields, batch, dim]. */
+int cafe_scores_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_scores, cafe_stream_t stream);
+
+/* sk_embedding_bag.py:199-208: for every lookup with d_ins != 0 whose id now reads hot,
+ * W_hot[slot] = W_cold[f][local_id % hash_size[f]] (pre-update cold row; local id). */
+int cafe_migrate_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
+                     const int32_t *d_ins, int batch, cafe_stream_t stream);
+
+/* backward of the forward + torch.optim.SGD on the two sparse gradients (dlrm_s_pytorch.py:1658):
+ * duplicates summed per row, then W -= lr * g.  d_que is the forward's routing. */
+int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_que, const float *d_grad_out,
+                          int batch, float lr, cafe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAFE_HIP_H */

@@ -1,0 +1,144 @@
+"""GPU parity of the HotSketch kernels against the reference's own traces (tests/golden) and against the
+CPU oracle on fresh seeded streams.  Bit-exact: ins[], que[], every slot, every scalar, free-list order."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import golden_names, ROOT
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+class _Np:
+    """Adapter: HotSketch with numpy in/out, the interface golden_util.replay expects."""
+
+    def __init__(self, sk):
+        self.sk = sk
+
+    def insert_val(self, ids, v):
+        return self.sk.insert_val(ids, v).cpu().numpy()
+
+    def insert(self, ids):
+        return self.sk.insert(ids).cpu().numpy()
+
+    def query(self, ids):
+        return self.sk.query(ids).cpu().numpy()
+
+    def state(self):
+        return self.sk.state()
+
+
+def _make(g, serial):
+    from cafe_amd.sketch import HotSketch
+    sk = HotSketch(int(g["lim"]), int(g["thr"]), int(g["adjust"]), float(g["alpha"]), int(g["lru_first"]))
+    sk.set_option("serial_insert", 1 if serial else 0)
+    return sk
+
+
+@pytest.mark.parametrize("serial", [1, 0], ids=["inorder", "parallel"])
+@pytest.mark.parametrize("name", golden_names())
+def test_reference_trace_on_gpu(name, serial, oracle_mod):
+    g = gu.load(name)
+    sk = _make(g, serial)
+    bad = gu.replay(g, _Np(sk), states_equal=oracle_mod.states_equal)
+    assert not bad, "\n".join(bad)
+
+
+def _stream(seed, n, space, a=1.08):
+    rng = np.random.default_rng(seed)
+    ids = ((rng.zipf(a, size=n) - 1) % space + 1).astype(np.int64)
+    v = (rng.random(n, dtype=np.float32) * np.float32(2.0)).astype(np.float32)
+    return ids, v
+
+
+@pytest.mark.parametrize("lim,thr,batch,calls,space", [
+    (2000, 4, 4096, 12, 50000),          # many ids per bucket, resets
+    (13505, 3, 8192, 8, 33762577),       # cfg2-sized sketch, one field's batch
+    (50000, 6, 65536, 4, 5000000),       # batches far beyond the reference's 16384 buffer
+])
+def test_fresh_streams_match_oracle(lim, thr, batch, calls, space, oracle_mod):
+    from cafe_amd.sketch import HotSketch
+    ora = oracle_mod.Oracle(lim, thr, 1, 1.0000005, 1)
+    sk = HotSketch(lim, thr, 1, 1.0000005, 1)
+    for c in range(calls):
+        ids, v = _stream(1000 + c, batch, space)
+        want = ora.insert_val(ids, v)
+        got = sk.insert_val(ids, v).cpu().numpy()
+        assert np.array_equal(got, want), f"call {c}: ins differs"
+        assert np.array_equal(sk.query(ids).cpu().numpy(), ora.query(ids)), f"call {c}: que differs"
+    assert not oracle_mod.states_equal(sk.state(), ora.state())
+
+
+def test_empty_and_tiny_batches(oracle_mod):
+    from cafe_amd.sketch import HotSketch
+    ora = oracle_mod.Oracle(100, 2, 1, 1.0, 1)
+    sk = HotSketch(100, 2, 1, 1.0, 1)
+    for ids in ([], [5], [5, 5], [0], [7, 0, 7]):
+        v = np.ones(len(ids), np.float32)
+        want = ora.insert_val(np.array(ids, np.int64), v)
+        got = sk.insert_val(np.array(ids, np.int64), v).cpu().numpy()
+        assert np.array_equal(got, want)
+    assert not oracle_mod.states_equal(sk.state(), ora.state())
+
+
+def test_state_roundtrip_and_file(tmp_path, oracle_mod):
+    from cafe_amd.sketch import HotSketch
+    g = gu.load("thr1_quirk")
+    sk = _make(g, 1)
+    assert not gu.replay(g, _Np(sk), check_state=False)
+    st = sk.state()
+    sk2 = _make(g, 1)
+    sk2.load_state_dict(st)
+    assert not oracle_mod.states_equal(sk2.state(), st)
+    p = tmp_path / "sk.bin"
+    sk.save(p)
+    sk3 = _make(g, 1)
+    sk3.load(p)
+    assert not oracle_mod.states_equal(sk3.state(), st)
+    # update(): free list rebuilt as the ascending unused slots
+    sk3.rebuild_free_list()
+    used = set(int(x) for x in np.concatenate([st["mdic"], st["ldic"]]) if x)
+    want = np.array([i for i in range(1, int(g["lim"])) if i not in used], np.uint32)
+    assert np.array_equal(sk3.state()["fifo"], want)
+
+
+_ABI_CHILD = r"""
+import ctypes, sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import golden_util as gu
+from cafe_amd import _lib
+L = _lib.load()
+g = gu.load("known_answer")
+i32p = ctypes.POINTER(ctypes.c_int); f32p = ctypes.POINTER(ctypes.c_float)
+# bind exactly as tricks/sk_embedding_bag.py:61-73 does
+L.batch_query.argtypes = [i32p, ctypes.c_int]; L.batch_query.restype = i32p
+L.batch_insert.argtypes = [i32p, ctypes.c_int]; L.batch_insert.restype = i32p
+L.batch_insert_val.argtypes = [i32p, f32p, ctypes.c_int]; L.batch_insert_val.restype = i32p
+L.init(int(g["lim"]), int(g["thr"]), int(g["adjust"]), float(g["alpha"]))
+for k, kind, ids, sc, out in gu.calls(g):
+    a = np.ascontiguousarray(ids.view(np.int32)); p = a.ctypes.data_as(i32p)
+    if kind == "insert_val":
+        s = np.ascontiguousarray(sc); r = L.batch_insert_val(p, s.ctypes.data_as(f32p), len(a))
+    elif kind == "insert":
+        r = L.batch_insert(p, len(a))
+    else:
+        r = L.batch_query(p, len(a))
+    got = np.ctypeslib.as_array(r, shape=(len(a),))
+    assert np.array_equal(got, out), (k, kind, got, out)
+u = np.array([7, 8, 9, 1007, 4242], np.uint32)
+assert abs(L.analyse(u.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 5) - 0.8) < 1e-12
+assert abs(L.analyse1(u.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), 5) - 0.8) < 1e-12
+L.update()
+print("ABI_OK")
+"""
+
+
+def test_reference_abi_drop_in():
+    """The g++-built sklib.so's entry points (sketch.cpp:300-327), bound the way the reference binds them."""
+    r = subprocess.run([sys.executable, "-c", _ABI_CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=300)
+    assert "ABI_OK" in r.stdout, r.stdout + r.stderr
