@@ -46,7 +46,7 @@ SYMBOLS = {
     "cafe_tables_destroy": (ctypes.c_int, [_vp]),
     "cafe_forward_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "cafe_scores_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
-    "cafe_migrate_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
+    "cafe_migrate_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "cafe_backward_sgd_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_float, _vp]),
 }
 

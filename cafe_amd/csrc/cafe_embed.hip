@@ -190,8 +190,8 @@ extern "C" int cafe_scores_dev(cafe_tables_t *t, const float *d_grad_out, int ba
 __global__ void k_migrate(const MainBucket *__restrict__ mt, FastMod fm1, float *__restrict__ w_hot,
                           float *const *__restrict__ w_cold, const int32_t *__restrict__ hash_size,
                           const int64_t *__restrict__ local_ids, const int32_t *__restrict__ gids,
-                          const int32_t *__restrict__ ins, int batch, int total, int dim) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+                          const int32_t *__restrict__ ins, int batch, int begin, int total, int dim) {
+    int i = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total || !ins[i]) return;
     const uint32_t x = (uint32_t)gids[i];
     const MainBucket &b = mt[fast_hash(x, fm1)];
@@ -205,11 +205,16 @@ __global__ void k_migrate(const MainBucket *__restrict__ mt, FastMod fm1, float 
 }
 
 extern "C" int cafe_migrate_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
-                                const int32_t *d_ins, int batch, cafe_stream_t stream) {
-    const int total = t->num_fields * batch;
-    hipLaunchKernelGGL(k_migrate, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_main,
+                                const int32_t *d_ins, int batch, int first_field, int n_fields, cafe_stream_t stream) {
+    if (first_field < 0 || n_fields < 0 || first_field + n_fields > t->num_fields) {
+        set_error("cafe_migrate_dev: field range [%d, %d) outside 0..%d", first_field, first_field + n_fields, t->num_fields);
+        return 1;
+    }
+    const int begin = first_field * batch, total = (first_field + n_fields) * batch;
+    if (total == begin) return 0;
+    hipLaunchKernelGGL(k_migrate, dim3((total - begin + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_main,
                        make_fastmod(s->n1), t->d_w_hot, t->d_w_cold, t->d_hash_size, d_local_ids, d_gids, d_ins, batch,
-                       total, t->dim);
+                       begin, total, t->dim);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }

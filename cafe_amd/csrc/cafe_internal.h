@@ -56,6 +56,8 @@ struct cafe_sketch {
     cafe::DevBuf ws_reset_keys, ws_reset_keys2, ws_reset_tmp, ws_reset_flags, ws_misc;
     cafe::ParWorkspace *par = nullptr;
     int32_t *h_pinned = nullptr;    // small pinned readback area
+    hipEvent_t ev_real_n = nullptr; // recorded after the async readback of real_n that ends every insert
+    bool real_n_pending = false;
 };
 
 struct cafe_tables {

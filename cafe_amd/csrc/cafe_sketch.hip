@@ -393,6 +393,7 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     CAFE_HIP_CHECK(hipMalloc(&s->d_fifo, sizeof(uint32_t) * (size_t)s->fifo_cap));
     CAFE_HIP_CHECK(hipMalloc(&s->d_state, sizeof(DevState)));
     CAFE_HIP_CHECK(hipHostMalloc((void **)&s->h_pinned, 256, hipHostMallocDefault));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_real_n, hipEventDisableTiming));
     if (s->ws_misc.reserve(4096)) return 1;
     CAFE_HIP_CHECK(hipMemset(s->d_main, 0, sizeof(MainBucket) * (size_t)s->n1));
     CAFE_HIP_CHECK(hipMemset(s->d_lru, 0, sizeof(LruBucket) * (size_t)s->n2));
@@ -409,6 +410,7 @@ extern "C" int cafe_sketch_destroy(cafe_sketch_t *s) {
     par_free(s);
     (void)hipFree(s->d_main); (void)hipFree(s->d_lru); (void)hipFree(s->d_fifo); (void)hipFree(s->d_state);
     if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+    if (s->ev_real_n) (void)hipEventDestroy(s->ev_real_n);
     s->ws_reset_keys.release(); s->ws_reset_keys2.release(); s->ws_reset_tmp.release();
     s->ws_reset_flags.release(); s->ws_misc.release();
     delete s;
@@ -422,8 +424,16 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
     return 0;
 }
 
+static int read_state(cafe_sketch *s, DevState *h);
+
 extern "C" int cafe_sketch_counters(cafe_sketch_t *s, int64_t *out8) {
+    DevState h;
+    if (read_state(s, &h)) return 1;
     memcpy(out8, s->counters, sizeof(s->counters));
+    out8[2] += h.pad[0];            // parallel calls that were handed to the in-order kernel
+    out8[1] -= h.pad[0];
+    out8[3] = h.pad[1];
+    out8[5] = h.pad[2];
     return 0;
 }
 
@@ -513,6 +523,7 @@ extern "C" int cafe_sketch_import(cafe_sketch_t *s, const int32_t *mval, const f
     CAFE_HIP_CHECK(hipMemcpy(s->d_state, &h, sizeof(h), hipMemcpyHostToDevice));
     s->flip = ints6[3]; s->batch_num = ints6[4]; s->decay = decay;
     s->real_n_ub = h.real_n;
+    s->real_n_pending = false;
     return 0;
 }
 
@@ -636,11 +647,14 @@ extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const flo
     int flip_now = 0;
     if (s->decay > kDecayV) { s->decay /= kDecayV; s->flip ^= 1; flip_now = 1; }
     hipLaunchKernelGGL(k_prologue, dim3(1), dim3(64), 0, st, s->d_state, flip_now, s->flip);
-    // sketch.cpp:291.  The host only syncs when its upper bound of real_n says a reset is possible.
+    // sketch.cpp:291.  real_n after the previous insert was copied to pinned memory behind that insert; waiting
+    // for that copy (normally long done: later kernels of the step were queued behind it) gives the exact value.
     if (s->adjust && (double)s->real_n_ub > s->lim * 1.2) {
-        CAFE_HIP_CHECK(hipMemcpyAsync(s->h_pinned, &s->d_state->real_n, 4, hipMemcpyDeviceToHost, st));
-        CAFE_HIP_CHECK(hipStreamSynchronize(st));
-        s->real_n_ub = s->h_pinned[0];
+        if (s->real_n_pending) {
+            CAFE_HIP_CHECK(hipEventSynchronize(s->ev_real_n));
+            s->real_n_pending = false;
+            s->real_n_ub = s->h_pinned[0];
+        }
         if ((double)s->real_n_ub > s->lim * 1.2) {
             if (run_reset(s, st)) return 1;
             s->real_n_ub = s->lim;
@@ -655,7 +669,12 @@ extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const flo
     } else {
         rc = par_insert(s, d_ids, d_scores, n, d_ins, st);
     }
-    s->real_n_ub += n;
+    s->real_n_ub += n;        // upper bound until the readback below is consumed
+    if (rc == 0 && s->adjust) {
+        CAFE_HIP_CHECK(hipMemcpyAsync(s->h_pinned, &s->d_state->real_n, 4, hipMemcpyDeviceToHost, st));
+        CAFE_HIP_CHECK(hipEventRecord(s->ev_real_n, st));
+        s->real_n_pending = true;
+    }
     return rc;
 }
 

@@ -118,9 +118,11 @@ int cafe_forward_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_
 int cafe_scores_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_scores, cafe_stream_t stream);
 
 /* sk_embedding_bag.py:199-208: for every lookup with d_ins != 0 whose id now reads hot,
- * W_hot[slot] = W_cold[f][local_id % hash_size[f]] (pre-update cold row; local id). */
+ * W_hot[slot] = W_cold[f][local_id % hash_size[f]] (pre-update cold row; local id).
+ * Arrays are the full [num_fields*batch] ones; only fields [first_field, first_field+n_fields) are visited,
+ * so a caller that inserts field by field (dlrm_s_pytorch.py:734-738) can migrate field by field too. */
 int cafe_migrate_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
-                     const int32_t *d_ins, int batch, cafe_stream_t stream);
+                     const int32_t *d_ins, int batch, int first_field, int n_fields, cafe_stream_t stream);
 
 /* backward of the forward + torch.optim.SGD on the two sparse gradients (dlrm_s_pytorch.py:1658):
  * duplicates summed per row, then W -= lr * g.  d_que is the forward's routing. */
