@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the CAFE hot path on MI355X: embedding lookups/s for
+forward (sketch query + hot/cold gather) + backward (scores, sketch insert, migration, sparse SGD).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2|...]
+
+One step = one pass of the hot path over one batch of synthetic Zipf(1.05) ids (ids, tables, sketch and
+the upstream gradient are resident in HBM before the timed region).  N > 1 is launched by
+torch.distributed.run, one rank per GPU; tables and sketch are hash-sharded by id and lookups travel by
+RCCL all-to-all (cafe_amd/sharded.py).  Rank 0 prints ONE JSON line.
+
+The default workload is cfg3 (BASELINE.json configs[2] tables: Criteo-Terabyte-shaped, ~880 M ids,
+26 fields, D=128, compress 0.001) because that is the configuration the north-star target is quoted on
+("at 1 GPU on Criteo-Terabyte-shaped synthetic data") and it fits one GPU; cfg2 is `--config cfg2`.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (samples); default: the config's")
+    ap.add_argument("--preheat", type=int, default=40, help="untimed steps that populate the sketch before warmup")
+    ap.add_argument("--lr", type=float, default=0.1)
+    ap.add_argument("--per-field-calls", action="store_true", help="one batch_insert_val per field (reference loop)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+# --------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N=1 only): the reference's sketch (oracle/_ref/sklib.so, built from the reference's
+# own sketch.cpp) or, where that is absent, the C port (oracle/liboracle.so), plus torch CPU ops for the
+# tables, on a bounded sample of the same workload.  Runs in a child process: the reference needs
+# MALLOC_PERTURB_ set at process start and keeps global state.
+# --------------------------------------------------------------------------------------------------
+def cpu_baseline_worker(args):
+    import ctypes
+    import torch
+    from cafe_amd.config import workload
+    wl = workload(args.config, args.batch or None)
+    F, B, D = wl.num_fields, wl.batch, wl.dim
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "sklib.so")
+    i32p, f32p = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)
+    if os.path.exists(ref_so) and B <= 16384:
+        kind = "reference"
+        L = ctypes.CDLL(ref_so)
+        L.init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+        L.batch_query.argtypes = [i32p, ctypes.c_int]; L.batch_query.restype = i32p
+        L.batch_insert_val.argtypes = [i32p, f32p, ctypes.c_int]; L.batch_insert_val.restype = i32p
+        devnull = os.open(os.devnull, os.O_WRONLY); saved = os.dup(1); os.dup2(devnull, 1)   # the reference prints
+        L.init(wl.hotn, wl.threshold, 1, wl.alpha)
+
+        def query(g):
+            return np.ctypeslib.as_array(L.batch_query(g.ctypes.data_as(i32p), len(g)), shape=(len(g),)).copy()
+
+        def insert(g, v):
+            return np.ctypeslib.as_array(L.batch_insert_val(g.ctypes.data_as(i32p), v.ctypes.data_as(f32p), len(g)),
+                                         shape=(len(g),)).copy()
+    else:
+        kind = "port"
+        from oracle.cafe_oracle import Oracle
+        sk = Oracle(wl.hotn, wl.threshold, 1, wl.alpha, 1)
+        saved = None
+
+        def query(g):
+            return sk.query(g)
+
+        def insert(g, v):
+            return sk.insert_val(g, v)
+
+    torch.manual_seed(0)
+    w_hot = torch.zeros(wl.hotn, D)
+    w_cold = [(torch.rand(h, D) * 2 - 1) * float(np.sqrt(1.0 / n)) for n, h in zip(wl.counts, wl.hash_sizes)]
+    ids_all = wl.make_ids(123, steps=4)
+    grad = torch.randn(F, B, D)
+    lr = args.lr
+    t0 = time.perf_counter()
+    steps = 0
+    sk_time = 0.0
+    while True:
+        ids = ids_all[steps % len(ids_all)]
+        # forward (sk_embedding_bag.py:119-152)
+        gids, ques, outs = [], [], []
+        for f in range(F):
+            g = np.ascontiguousarray((ids[f] + wl.offsets[f]).astype(np.int32))
+            ts = time.perf_counter(); q = query(g); sk_time += time.perf_counter() - ts
+            qt = torch.from_numpy(q.astype(np.int64))
+            hot = qt < 0
+            dic = qt.abs()
+            out = torch.where(hot[:, None], w_hot[dic % wl.hotn], w_cold[f][dic % wl.hash_sizes[f]])
+            gids.append(g); ques.append((hot, dic)); outs.append(out)
+        # backward: scores, insert, migration (sk_embedding_bag.py:173-208), then SGD (dlrm_s_pytorch.py:1658)
+        for f in range(F):
+            gn = torch.linalg.vector_norm(grad[f], dim=1)
+            sc = (gn * B / gn.sum()).numpy()
+            ts = time.perf_counter(); ins = insert(gids[f], np.ascontiguousarray(sc, np.float32)); sk_time += time.perf_counter() - ts
+            idx = np.nonzero(ins)[0]
+            if len(idx):
+                qa = query(gids[f])
+                for i in idx:
+                    if qa[i] < 0:
+                        w_hot[-int(qa[i])] = w_cold[f][int(ids[f][i]) % wl.hash_sizes[f]]
+        for f in range(F):
+            hot, dic = ques[f]
+            w_hot.index_add_(0, (dic[hot] % wl.hotn), grad[f][hot], alpha=-lr)
+            w_cold[f].index_add_(0, (dic[~hot] % wl.hash_sizes[f]), grad[f][~hot], alpha=-lr)
+        steps += 1
+        if time.perf_counter() - t0 > args.cpu_seconds and steps >= 2:
+            break
+    dt = time.perf_counter() - t0
+    if saved is not None:
+        os.dup2(saved, 1)
+    print(json.dumps({"value": steps * F * B / dt, "unit": "lookups/s", "cores": torch.get_num_threads(), "kind": kind,
+                      "sample": f"{steps} steps of {wl.name} (batch {B}, {F} fields, D={D}) in {dt:.1f} s; sketch calls "
+                                f"single-threaded ({sk_time / dt * 100:.0f}% of the time), table ops torch CPU"}))
+
+
+def run_cpu_baseline(args):
+    env = dict(os.environ, MALLOC_PERTURB_="165")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--config", args.config,
+           "--cpu-seconds", str(args.cpu_seconds), "--lr", str(args.lr)]
+    if args.batch:
+        cmd += ["--batch", str(args.batch)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.cpu_seconds * 6 + 120)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:          # the baseline is a reported number, never a reason to lose the GPU result
+        return {"value": None, "unit": "lookups/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"[:200]}
+
+
+# --------------------------------------------------------------------------------------------------
+def main():
+    args = parse()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(args)
+        return
+    import torch
+    import torch.distributed as dist
+    from cafe_amd.config import workload
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    wl = workload(args.config, args.batch or None)
+    F, B, D = wl.num_fields, wl.batch, wl.dim
+    fused = not args.per_field_calls
+
+    if world == 1:
+        from cafe_amd.collection import CafeEmbeddingCollection
+        eng = CafeEmbeddingCollection(wl.counts, D, wl.hotn, wl.hash_sizes, wl.offsets, threshold=wl.threshold,
+                                      alpha=wl.alpha, seed=1)
+    else:
+        from cafe_amd.sharded import ShardedCafeEmbedding
+        eng = ShardedCafeEmbedding(wl.counts, D, wl.hotn, wl.hash_sizes, wl.offsets, threshold=wl.threshold,
+                                   alpha=wl.alpha, seed=1)
+
+    nb = 8
+    ids_host = wl.make_ids(123 + rank, steps=nb)
+    ids_dev = [torch.from_numpy(ids_host[i]).cuda() for i in range(nb)]
+    grad = torch.randn(F, B, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5 + rank))
+    out = torch.empty(F, B, D, device="cuda")
+
+    ev_f0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_f1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i, timed_idx=None):
+        ids = ids_dev[i % nb]
+        if timed_idx is not None:
+            ev_f0[timed_idx].record()
+        eng.forward(ids, out=out)
+        if timed_idx is not None:
+            ev_f1[timed_idx].record()
+        eng.backward_update(grad, args.lr, per_field_calls=not fused)
+
+    it = 0
+    for _ in range(args.preheat + args.warmup):
+        step(it); it += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(it, k); it += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fwd_ms = sum(a.elapsed_time(b) for a, b in zip(ev_f0, ev_f1)) / args.steps
+
+    if rank == 0:
+        lookups = F * B * world * args.steps
+        value = lookups / dt
+        # dominant kernel: the fused query+gather (k_forward).  Algorithmic bytes per lookup in that kernel
+        # (SURVEY.md 8(d)): id 4 + bucket probe 52 + selected row 4D + output row 4D.
+        fwd_bytes = F * B * (56 + 8 * D) if world == 1 else None
+        roof = None
+        if world == 1:
+            ach = fwd_bytes / (fwd_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_forward (fused sketch query + hot/cold row gather)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": None, "avg_launch_us": round(fwd_ms * 1e3, 2),
+                    "whole_step_frac": round(value * wl.bytes_per_lookup() / 1e9 / HBM_PEAK_GBS, 4)}
+        res = {
+            "metric": "embedding lookups/sec (fwd+bwd+sketch)", "value": round(value, 1), "unit": "lookups/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+i32",
+            "data": "synthetic Zipf(1.05) ids, random-init tables, random upstream gradient",
+            "config": {"workload": f"{wl.name}: {F} fields, {sum(wl.counts)} ids, D={D}, batch {B}/GPU, hotn {wl.hotn}, "
+                                   f"compress {wl.compress_rate}, hash-rate {wl.hash_rate}, threshold {wl.threshold}",
+                       "sketch_calls": "one per step" if fused else "one per field",
+                       "parallelism": "single GPU" if world == 1 else f"id-hash sharded x{world}, RCCL all-to-all",
+                       "preheat_steps": args.preheat},
+            "sketch": eng.sketch.counters() if hasattr(eng, "sketch") else None,
+        }
+        if roof:
+            res["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = run_cpu_baseline(args)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

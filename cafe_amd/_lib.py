@@ -48,6 +48,10 @@ SYMBOLS = {
     "cafe_scores_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "cafe_migrate_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "cafe_backward_sgd_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_float, _vp]),
+    "cafe_forward_gid_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "cafe_migrate_gid_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
+    "cafe_backward_sgd_gid_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_float, _vp]),
+    "cafe_grad_norm_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
 }
 
 _LIB = None
@@ -64,6 +68,9 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise CafeError(f"{LIB_PATH} not found: build it with `make -C cafe_amd/csrc` "
                             "(or __graft_entry__.build()); there is no CPU fallback")
+        # torch ships its own HIP runtime; load it first so that this library binds to the same runtime
+        # instance (two runtimes in one process do not share devices, streams or allocations)
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)           # AttributeError if a declared symbol is not exported

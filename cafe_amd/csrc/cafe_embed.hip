@@ -68,15 +68,17 @@ template <int LPG>
 __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ mt, FastMod fm1,
                                                  const float *__restrict__ w_hot, float *const *__restrict__ w_cold,
                                                  const int64_t *__restrict__ id_offset, const int32_t *__restrict__ hash_size,
-                                                 const int64_t *__restrict__ local_ids, int batch, int total, int dim,
+                                                 const int64_t *__restrict__ local_ids,
+                                                 const int32_t *__restrict__ in_gids, const int32_t *__restrict__ fields,
+                                                 int batch, int total, int dim,
                                                  int32_t *__restrict__ gids, int32_t *__restrict__ que,
                                                  float *__restrict__ out) {
     const int lig = threadIdx.x % LPG;
     const int groups = (gridDim.x * blockDim.x) / LPG;
     const int dim4 = dim >> 2;
     for (int i = (blockIdx.x * blockDim.x + threadIdx.x) / LPG; i < total; i += groups) {
-        const int f = i / batch;
-        const int32_t g = (int32_t)(local_ids[i] + id_offset[f]);      // sk_embedding_bag.py:103
+        const int f = fields ? fields[i] : i / batch;
+        const int32_t g = local_ids ? (int32_t)(local_ids[i] + id_offset[f]) : in_gids[i];      // sk_embedding_bag.py:103
         const uint32_t x = (uint32_t)g;
         const int4 *p = reinterpret_cast<const int4 *>(&mt[fast_hash(x, fm1)]);
         const int4 v = p[0], d = p[1];
@@ -85,17 +87,17 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
         // hot: W_h[|q| % hotn] = W_h[slot]; cold: W_hash[|q| % hash_size] (sk_embedding_bag.py:134-150)
         const float *row = q < 0 ? w_hot + (size_t)(-q) * dim
                                  : w_cold[f] + (size_t)((uint32_t)q % (uint32_t)hash_size[f]) * dim;
-        if (lig == 0) { gids[i] = g; que[i] = q; }
+        if (lig == 0) { if (gids) gids[i] = g; que[i] = q; }
         float4 *o = reinterpret_cast<float4 *>(out + (size_t)i * dim);
         for (int c = lig; c < dim4; c += LPG) o[c] = reinterpret_cast<const float4 *>(row)[c];
     }
 }
 
-extern "C" int cafe_forward_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, int batch,
-                                int32_t *d_gids, int32_t *d_que, float *d_out, cafe_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
-    const long total_l = (long)t->num_fields * batch;
-    if (batch <= 0 || total_l > 0x7fffffffL / 4) { set_error("cafe_forward_dev: bad batch %d", batch); return 1; }
+static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_in_gids,
+                          const int32_t *d_fields, int batch, long total_l, int32_t *d_gids, int32_t *d_que, float *d_out,
+                          hipStream_t st) {
+    if (total_l == 0) return 0;
+    if (batch <= 0 || total_l < 0 || total_l > 0x7fffffffL / 4) { set_error("cafe forward: bad size %ld", total_l); return 1; }
     const int total = (int)total_l;
     const int lpg = lanes_per_row(t->dim);
     const long threads = (long)total * lpg;
@@ -103,7 +105,7 @@ extern "C" int cafe_forward_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_
     FastMod fm1 = make_fastmod(s->n1);
 #define CAFE_FWD(L)                                                                                              \
     hipLaunchKernelGGL(k_forward<L>, dim3(blocks), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold,     \
-                       t->d_id_offset, t->d_hash_size, d_local_ids, batch, total, t->dim, d_gids, d_que, d_out)
+                       t->d_id_offset, t->d_hash_size, d_local_ids, d_in_gids, d_fields, batch, total, t->dim, d_gids, d_que, d_out)
     switch (lpg) {
         case 1: CAFE_FWD(1); break;
         case 2: CAFE_FWD(2); break;
@@ -116,6 +118,17 @@ extern "C" int cafe_forward_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_
 #undef CAFE_FWD
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+extern "C" int cafe_forward_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, int batch,
+                                int32_t *d_gids, int32_t *d_que, float *d_out, cafe_stream_t stream) {
+    return forward_common(s, t, d_local_ids, nullptr, nullptr, batch, (long)t->num_fields * batch, d_gids, d_que, d_out,
+                          (hipStream_t)stream);
+}
+
+extern "C" int cafe_forward_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_fields,
+                                    int n, int32_t *d_que, float *d_out, cafe_stream_t stream) {
+    return forward_common(s, t, nullptr, d_gids, d_fields, 1, (long)n, nullptr, d_que, d_out, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -141,7 +154,8 @@ __global__ void __launch_bounds__(256) k_grad_norm(const float *__restrict__ g, 
 }
 
 // one workgroup per field: fixed-order sum of the field's norms, then s_i = gn_i * batch / sum
-__global__ void __launch_bounds__(1024) k_field_scale(const float *__restrict__ gn, int batch, float *__restrict__ scores) {
+__global__ void __launch_bounds__(1024) k_field_scale(const float *__restrict__ gn, int batch, float *__restrict__ scores,
+                                                      float *__restrict__ sums) {
     __shared__ float part[1024];
     const int f = blockIdx.x;
     const float *src = gn + (size_t)f * batch;
@@ -154,16 +168,17 @@ __global__ void __launch_bounds__(1024) k_field_scale(const float *__restrict__ 
         __syncthreads();
     }
     const float sum = part[0];
+    if (sums && threadIdx.x == 0) sums[f] = sum;
+    if (!scores) return;
     const float nb = (float)batch;
     float *dst = scores + (size_t)f * batch;
     for (int i = threadIdx.x; i < batch; i += blockDim.x) dst[i] = src[i] * nb / sum;
 }
 
-extern "C" int cafe_scores_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_scores, cafe_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
+static int scores_common(cafe_tables_t *t, const float *d_grad_out, int batch, float *gn, float *d_scores, float *d_sums,
+                         hipStream_t st) {
     const int total = t->num_fields * batch;
-    if (t->ws_norm.reserve((size_t)total * 4 + 16)) return 1;
-    float *gn = t->ws_norm.as<float>();
+    if (total <= 0) return 0;
     const int lpg = lanes_per_row(t->dim);
     const long threads = (long)total * lpg;
     const int blocks = (int)std::min<long>((threads + 255) / 256, 256 * 16);
@@ -178,9 +193,19 @@ extern "C" int cafe_scores_dev(cafe_tables_t *t, const float *d_grad_out, int ba
         default: CAFE_GN(64); break;
     }
 #undef CAFE_GN
-    hipLaunchKernelGGL(k_field_scale, dim3(t->num_fields), dim3(1024), 0, st, gn, batch, d_scores);
+    hipLaunchKernelGGL(k_field_scale, dim3(t->num_fields), dim3(1024), 0, st, gn, batch, d_scores, d_sums);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+extern "C" int cafe_scores_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_scores, cafe_stream_t stream) {
+    if (t->ws_norm.reserve((size_t)t->num_fields * batch * 4 + 16)) return 1;
+    return scores_common(t, d_grad_out, batch, t->ws_norm.as<float>(), d_scores, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int cafe_grad_norm_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_norms, float *d_field_sums,
+                                  cafe_stream_t stream) {
+    return scores_common(t, d_grad_out, batch, d_norms, nullptr, d_field_sums, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -189,7 +214,9 @@ extern "C" int cafe_scores_dev(cafe_tables_t *t, const float *d_grad_out, int ba
 // ------------------------------------------------------------------------------------------------
 __global__ void k_migrate(const MainBucket *__restrict__ mt, FastMod fm1, float *__restrict__ w_hot,
                           float *const *__restrict__ w_cold, const int32_t *__restrict__ hash_size,
+                          const int64_t *__restrict__ id_offset,
                           const int64_t *__restrict__ local_ids, const int32_t *__restrict__ gids,
+                          const int32_t *__restrict__ fields,
                           const int32_t *__restrict__ ins, int batch, int begin, int total, int dim) {
     int i = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total || !ins[i]) return;
@@ -197,8 +224,9 @@ __global__ void k_migrate(const MainBucket *__restrict__ mt, FastMod fm1, float 
     const MainBucket &b = mt[fast_hash(x, fm1)];
     const int32_t q = query_bucket(b.val, b.dic, x);        // the re-query of sk_embedding_bag.py:201-204
     if (q >= 0) return;
-    const int f = i / batch;
-    const int64_t src_row = local_ids[i] % (int64_t)hash_size[f];     // LOCAL id: sk_embedding_bag.py:207
+    const int f = fields ? fields[i] : i / batch;
+    const int64_t local = local_ids ? local_ids[i] : (int64_t)gids[i] - id_offset[f];
+    const int64_t src_row = local % (int64_t)hash_size[f];     // LOCAL id: sk_embedding_bag.py:207
     const float4 *src = reinterpret_cast<const float4 *>(w_cold[f] + (size_t)src_row * dim);
     float4 *dst = reinterpret_cast<float4 *>(w_hot + (size_t)(-q) * dim);
     for (int c = 0; c < (dim >> 2); ++c) dst[c] = src[c];
@@ -213,8 +241,18 @@ extern "C" int cafe_migrate_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_
     const int begin = first_field * batch, total = (first_field + n_fields) * batch;
     if (total == begin) return 0;
     hipLaunchKernelGGL(k_migrate, dim3((total - begin + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_main,
-                       make_fastmod(s->n1), t->d_w_hot, t->d_w_cold, t->d_hash_size, d_local_ids, d_gids, d_ins, batch,
-                       begin, total, t->dim);
+                       make_fastmod(s->n1), t->d_w_hot, t->d_w_cold, t->d_hash_size, t->d_id_offset, d_local_ids, d_gids,
+                       nullptr, d_ins, batch, begin, total, t->dim);
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int cafe_migrate_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_fields,
+                                    const int32_t *d_ins, int n, cafe_stream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_migrate, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_main,
+                       make_fastmod(s->n1), t->d_w_hot, t->d_w_cold, t->d_hash_size, t->d_id_offset, nullptr, d_gids,
+                       d_fields, d_ins, 1, 0, n, t->dim);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -225,7 +263,7 @@ extern "C" int cafe_migrate_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_
 // (dlrm_s_pytorch.py:1658).  Here: unified row keys -> sort -> segment sums -> one read-modify-write per
 // touched row.  Segments that cross a chunk border finish with float atomics.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_row_keys(const int32_t *__restrict__ gids, const int32_t *__restrict__ que,
+__global__ void k_row_keys(const int32_t *__restrict__ fields, const int32_t *__restrict__ que,
                            const int32_t *__restrict__ hash_size, const int64_t *__restrict__ cold_base, int hotn,
                            int batch, int total, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -235,16 +273,16 @@ __global__ void k_row_keys(const int32_t *__restrict__ gids, const int32_t *__re
     if (q < 0) {
         k = (uint32_t)(-q) % (uint32_t)hotn;
     } else {
-        const int f = i / batch;
+        const int f = fields ? fields[i] : i / batch;
         k = (uint32_t)hotn + (uint32_t)cold_base[f] + (uint32_t)q % (uint32_t)hash_size[f];
     }
-    (void)gids;
     keys[i] = k;
     vals[i] = (uint32_t)i;
 }
 
 template <int LPG, int CHUNK>
 __global__ void __launch_bounds__(256) k_segment_sgd(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                     const int32_t *__restrict__ fields,
                                                      const float *__restrict__ grad, float *__restrict__ w_hot,
                                                      float *const *__restrict__ w_cold, const int64_t *__restrict__ cold_base,
                                                      int hotn, int batch, int total, int dim, float lr) {
@@ -278,7 +316,7 @@ __global__ void __launch_bounds__(256) k_segment_sgd(const uint32_t *__restrict_
         if (key < (uint32_t)hotn) {
             row = w_hot + (size_t)key * dim;
         } else {
-            const int f = (int)(vals[s] / (uint32_t)batch);
+            const int f = fields ? fields[vals[s]] : (int)(vals[s] / (uint32_t)batch);
             row = w_cold[f] + (size_t)((int64_t)(key - (uint32_t)hotn) - cold_base[f]) * dim;
         }
 #pragma unroll
@@ -301,17 +339,16 @@ __global__ void __launch_bounds__(256) k_segment_sgd(const uint32_t *__restrict_
     }
 }
 
-extern "C" int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_que,
-                                     const float *d_grad_out, int batch, float lr, cafe_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
-    const int total = t->num_fields * batch;
+static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,
+                           int batch, int total, float lr, hipStream_t st) {
+    if (total <= 0) return 0;
     const int64_t rows = (int64_t)t->hotn + t->total_cold_rows;
     if (rows >= (int64_t)0xFFFFFFFFLL) { set_error("cafe_backward_sgd_dev: more than 2^32 table rows"); return 1; }
     if (t->ws_bwd_a.reserve((size_t)total * 4) || t->ws_bwd_b.reserve((size_t)total * 4) ||
         t->ws_bwd_c.reserve((size_t)total * 4) || t->ws_bwd_d.reserve((size_t)total * 4)) return 1;
     uint32_t *k0 = t->ws_bwd_a.as<uint32_t>(), *v0 = t->ws_bwd_b.as<uint32_t>();
     uint32_t *k1 = t->ws_bwd_c.as<uint32_t>(), *v1 = t->ws_bwd_d.as<uint32_t>();
-    hipLaunchKernelGGL(k_row_keys, dim3((total + 255) / 256), dim3(256), 0, st, d_gids, d_que, t->d_hash_size,
+    hipLaunchKernelGGL(k_row_keys, dim3((total + 255) / 256), dim3(256), 0, st, d_fields, d_que, t->d_hash_size,
                        t->d_cold_base, t->hotn, batch, total, k0, v0);
     int bits = 1;
     while (bits < 32 && ((int64_t)1 << bits) < rows) ++bits;
@@ -326,7 +363,7 @@ extern "C" int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, co
     const long threads = (long)chunks * lpg;
     const int blocks = (int)((threads + 255) / 256);
 #define CAFE_SEG(L)                                                                                               \
-    hipLaunchKernelGGL((k_segment_sgd<L, CH>), dim3(blocks), dim3(256), 0, st, k1, v1, d_grad_out, t->d_w_hot,     \
+    hipLaunchKernelGGL((k_segment_sgd<L, CH>), dim3(blocks), dim3(256), 0, st, k1, v1, d_fields, d_grad_out, t->d_w_hot, \
                        t->d_w_cold, t->d_cold_base, t->hotn, batch, total, t->dim, lr)
     switch (lpg) {
         case 1: CAFE_SEG(1); break;
@@ -340,4 +377,15 @@ extern "C" int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, co
 #undef CAFE_SEG
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+extern "C" int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_que,
+                                     const float *d_grad_out, int batch, float lr, cafe_stream_t stream) {
+    (void)d_gids;
+    return backward_common(t, nullptr, d_que, d_grad_out, batch, t->num_fields * batch, lr, (hipStream_t)stream);
+}
+
+extern "C" int cafe_backward_sgd_gid_dev(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que,
+                                         const float *d_grad_out, int n, float lr, cafe_stream_t stream) {
+    return backward_common(t, d_fields, d_que, d_grad_out, 1, n, lr, (hipStream_t)stream);
 }

@@ -129,6 +129,20 @@ int cafe_migrate_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_
 int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_que, const float *d_grad_out,
                           int batch, float lr, cafe_stream_t stream);
 
+/* ---- the same four steps for lookups in arbitrary order (each with its own field index), which is what
+ *      a shard owner receives from its peers in the multi-GPU path (no reference
+ *      counterpart: the reference is single-device).  local id = gid - id_offset[field]. ---- */
+int cafe_forward_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_fields, int n,
+                         int32_t *d_que, float *d_out, cafe_stream_t stream);
+int cafe_migrate_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_fields,
+                         const int32_t *d_ins, int n, cafe_stream_t stream);
+int cafe_backward_sgd_gid_dev(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,
+                              int n, float lr, cafe_stream_t stream);
+/* First half of cafe_scores_dev: d_norms[f*batch+i] = ||g_i||, d_field_sums[f] = sum_i ||g_i|| (fixed order), so that
+ * ranks can all-reduce the sums before scaling (sk_embedding_bag.py:178-189 over the global batch). */
+int cafe_grad_norm_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_norms, float *d_field_sums,
+                       cafe_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
