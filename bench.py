@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (samples); default: the config's")
     ap.add_argument("--preheat", type=int, default=40, help="untimed steps that populate the sketch before warmup")
     ap.add_argument("--lr", type=float, default=0.1)
+    ap.add_argument("--zipf-a", type=float, default=1.05, help="Zipf exponent of the id streams (<= 1: uniform ids; diagnostics)")
     ap.add_argument("--per-field-calls", action="store_true", help="one batch_insert_val per field (reference loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -178,7 +179,7 @@ def main():
                                    alpha=wl.alpha, seed=1)
 
     nb = 8
-    ids_host = wl.make_ids(123 + rank, steps=nb)
+    ids_host = wl.make_ids(123 + rank, steps=nb, a=args.zipf_a)
     ids_dev = [torch.from_numpy(ids_host[i]).cuda() for i in range(nb)]
     grad = torch.randn(F, B, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5 + rank))
     out = torch.empty(F, B, D, device="cuda")

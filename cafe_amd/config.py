@@ -70,7 +70,7 @@ class Workload:
         out = np.empty((steps, self.num_fields, self.batch), dtype=np.int64)
         for s in range(steps):
             for f, n in enumerate(self.counts):
-                loc = (rng.zipf(a, size=self.batch) - 1) % n
+                loc = (rng.zipf(a, size=self.batch) - 1) % n if a > 1.0 else rng.integers(0, n, size=self.batch)
                 if f == 0:
                     loc = np.maximum(loc, 1) if n > 1 else loc
                 out[s, f] = loc

@@ -77,17 +77,80 @@ __device__ inline int fast_hash(uint32_t x, FastMod f) {
 // sketch.cpp:130-140: float score / double constant, rounded back to float.
 __device__ inline float decay_once(float c) { return (float)((double)c / kDecayV); }
 
+// ---- register form of a bucket ---------------------------------------------------------------------
+// Named scalar members on purpose: a bucket copy indexed with a runtime slot number is placed in scratch
+// memory by hipcc (seen in the ISA: scratch_load/store with a VGPR index), which turns every step of a
+// bucket owner's replay loop into memory round trips.  Slot access goes through select chains instead.
+struct MainR {
+    int32_t v0, v1, v2, v3;     // val
+    int32_t d0, d1, d2, d3;     // dic
+    float c0, c1, c2, c3;       // cnt
+    uint32_t flip;
+};
+struct LruR {
+    int32_t v0, v1, v2, v3;
+    int32_t d0, d1, d2, d3;
+    float c0, c1, c2, c3;
+    int32_t t0, t1, t2, t3;
+    uint32_t flip;
+};
+
+__device__ inline int32_t sel4(int32_t a, int32_t b, int32_t c, int32_t d, int i) { return i == 0 ? a : i == 1 ? b : i == 2 ? c : d; }
+__device__ inline float sel4f(float a, float b, float c, float d, int i) { return i == 0 ? a : i == 1 ? b : i == 2 ? c : d; }
+// value selects, not conditional stores: hipcc merges conditional stores to neighbouring members into one
+// store through a selected address, which again forces the bucket copy into scratch memory
+#define CAFE_SET4(a0, a1, a2, a3, i, v)                                    \
+    do {                                                                   \
+        const int i_ = (i);                                                \
+        const auto v_ = (v);                                               \
+        a0 = i_ == 0 ? v_ : a0; a1 = i_ == 1 ? v_ : a1;                    \
+        a2 = i_ == 2 ? v_ : a2; a3 = i_ == 3 ? v_ : a3;                    \
+    } while (0)
+
+__device__ inline void load_main(MainR &b, const MainBucket *src) {
+    const int4 *p = reinterpret_cast<const int4 *>(src);
+    const int4 v = p[0], d = p[1], c = p[2];
+    b.v0 = v.x; b.v1 = v.y; b.v2 = v.z; b.v3 = v.w;
+    b.d0 = d.x; b.d1 = d.y; b.d2 = d.z; b.d3 = d.w;
+    b.c0 = __int_as_float(c.x); b.c1 = __int_as_float(c.y); b.c2 = __int_as_float(c.z); b.c3 = __int_as_float(c.w);
+    b.flip = src->flip;
+}
+// `tag` goes to pad[0]: unused in the tables, the bucket index in the staging copies of the parallel insert
+__device__ inline void store_main(MainBucket *dst, const MainR &b, int32_t tag = 0) {
+    int4 *p = reinterpret_cast<int4 *>(dst);
+    p[0] = make_int4(b.v0, b.v1, b.v2, b.v3);
+    p[1] = make_int4(b.d0, b.d1, b.d2, b.d3);
+    p[2] = make_int4(__float_as_int(b.c0), __float_as_int(b.c1), __float_as_int(b.c2), __float_as_int(b.c3));
+    p[3] = make_int4((int)b.flip, tag, 0, 0);
+}
+__device__ inline void load_lru(LruR &b, const LruBucket *src) {
+    const int4 *p = reinterpret_cast<const int4 *>(src);
+    const int4 v = p[0], d = p[1], c = p[2], t = p[3];
+    b.v0 = v.x; b.v1 = v.y; b.v2 = v.z; b.v3 = v.w;
+    b.d0 = d.x; b.d1 = d.y; b.d2 = d.z; b.d3 = d.w;
+    b.c0 = __int_as_float(c.x); b.c1 = __int_as_float(c.y); b.c2 = __int_as_float(c.z); b.c3 = __int_as_float(c.w);
+    b.t0 = t.x; b.t1 = t.y; b.t2 = t.z; b.t3 = t.w;
+    b.flip = src->flip;
+}
+__device__ inline void store_lru(LruBucket *dst, const LruR &b, int32_t tag = 0) {
+    int4 *p = reinterpret_cast<int4 *>(dst);
+    p[0] = make_int4(b.v0, b.v1, b.v2, b.v3);
+    p[1] = make_int4(b.d0, b.d1, b.d2, b.d3);
+    p[2] = make_int4(__float_as_int(b.c0), __float_as_int(b.c1), __float_as_int(b.c2), __float_as_int(b.c3));
+    p[3] = make_int4(b.t0, b.t1, b.t2, b.t3);
+    p[4] = make_int4((int)b.flip, tag, 0, 0);
+}
+
 template <class B>
 __device__ inline void sync_flip(B &b, uint32_t gflip) {
     if (b.flip != gflip) {
         b.flip = gflip;
-#pragma unroll
-        for (int i = 0; i < kSlots; ++i) b.cnt[i] = decay_once(b.cnt[i]);
+        b.c0 = decay_once(b.c0); b.c1 = decay_once(b.c1); b.c2 = decay_once(b.c2); b.c3 = decay_once(b.c3);
     }
 }
 
 // A move of an entry from the LRU table into the main table (the reference's Insert(), sketch.cpp:232-259),
-// requested by lru_insert and carried out on the target main bucket by whoever owns it.
+// requested by the LRU transition and carried out on the target main bucket by whoever owns it.
 struct MoveReq {
     int32_t kind;       // 0 none, 1 promotion of the inserted id itself, 2 eviction of another id
     uint32_t x;
@@ -95,41 +158,59 @@ struct MoveReq {
     int32_t dic;
 };
 
+// first slot whose id equals x, or -1 (sketch.cpp:214-215, 120-121: the scan stops at the first match)
+template <class B>
+__device__ inline int find_slot(const B &b, uint32_t x) {
+    int hit = -1;
+    if ((uint32_t)b.v3 == x) hit = 3;
+    if ((uint32_t)b.v2 == x) hit = 2;
+    if ((uint32_t)b.v1 == x) hit = 1;
+    if ((uint32_t)b.v0 == x) hit = 0;
+    return hit;
+}
+
 // sketch.cpp:211-229, the main-table half of insert().  Returns -1 on a miss, else the value of ins[i].
 template <class C>
-__device__ inline int main_probe(MainBucket &b, uint32_t x, float c, float thr, C &ctx) {
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i) {
-        if ((uint32_t)b.val[i] == x) {
-            b.cnt[i] += c;
-            float now = b.cnt[i];
-            int got = 0;
-            if (now >= thr && now - c < thr) ctx.crossed();
-            if (now >= thr && !b.dic[i] && ctx.can_pop()) { b.dic[i] = ctx.pop(); got = 1; }
-            return got;
-        }
-    }
-    return -1;
+__device__ inline int main_probe(MainR &b, uint32_t x, float c, float thr, C &ctx) {
+    const int i = find_slot(b, x);
+    if (i < 0) return -1;
+    const float now = sel4f(b.c0, b.c1, b.c2, b.c3, i) + c;
+    int32_t dic = sel4(b.d0, b.d1, b.d2, b.d3, i);
+    int got = 0;
+    if (now >= thr && now - c < thr) ctx.crossed();
+    if (now >= thr && !dic && ctx.can_pop()) { dic = ctx.pop(); got = 1; }
+    CAFE_SET4(b.c0, b.c1, b.c2, b.c3, i, now);
+    CAFE_SET4(b.d0, b.d1, b.d2, b.d3, i, dic);
+    return got;
 }
 
 // sketch.cpp:232-259 Insert(): returns 1 if the entry was placed, 0 if it was dropped.
 template <class C>
-__device__ inline int main_move(MainBucket &b, uint32_t x, float c, int32_t dic, C &ctx) {
+__device__ inline int main_move(MainR &b, uint32_t x, float c, int32_t dic, C &ctx) {
+    // the reference scans slots in order: the first empty slot takes the entry; the running minimum only
+    // matters if no slot is empty (strict <, first index wins ties; start value 1e9)
+    int empty = -1;
+    if (b.v3 == 0) empty = 3;
+    if (b.v2 == 0) empty = 2;
+    if (b.v1 == 0) empty = 1;
+    if (b.v0 == 0) empty = 0;
+    if (empty >= 0) {
+        CAFE_SET4(b.v0, b.v1, b.v2, b.v3, empty, (int32_t)x);
+        CAFE_SET4(b.c0, b.c1, b.c2, b.c3, empty, c);
+        CAFE_SET4(b.d0, b.d1, b.d2, b.d3, empty, dic);
+        return 1;
+    }
     int lo = -1;
     float lo_cnt = 1e9f;
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i) {
-        if (b.val[i] == 0) { b.val[i] = (int32_t)x; b.cnt[i] = c; b.dic[i] = dic; return 1; }
-        if (b.cnt[i] < lo_cnt) { lo_cnt = b.cnt[i]; lo = i; }
-    }
-    if (lo < 0) lo = 0;     // all scores >= 1e9: out of bounds in the reference; fenced like the oracle
-    // static indexing only (no runtime-indexed register arrays)
-    int hot = 0;
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i) if (i == lo) hot = b.dic[i];
-    if (!hot) {
-#pragma unroll
-        for (int i = 0; i < kSlots; ++i) if (i == lo) { b.cnt[i] += c; b.val[i] = (int32_t)x; b.dic[i] = dic; }
+    if (b.c0 < lo_cnt) { lo_cnt = b.c0; lo = 0; }
+    if (b.c1 < lo_cnt) { lo_cnt = b.c1; lo = 1; }
+    if (b.c2 < lo_cnt) { lo_cnt = b.c2; lo = 2; }
+    if (b.c3 < lo_cnt) { lo_cnt = b.c3; lo = 3; }
+    if (lo < 0) { lo = 0; lo_cnt = b.c0; }     // all scores >= 1e9: out of bounds in the reference; fenced like the oracle
+    if (!sel4(b.d0, b.d1, b.d2, b.d3, lo)) {
+        CAFE_SET4(b.c0, b.c1, b.c2, b.c3, lo, lo_cnt + c);
+        CAFE_SET4(b.v0, b.v1, b.v2, b.v3, lo, (int32_t)x);
+        CAFE_SET4(b.d0, b.d1, b.d2, b.d3, lo, dic);
         return 1;
     }
     if (dic != 0) ctx.push(dic);
@@ -142,64 +223,64 @@ __device__ inline int main_move(MainBucket &b, uint32_t x, float c, int32_t dic,
 //   miss: lru_evict() fills mv (kind 2)       -> caller performs mv          -> lru_place() [tick, pop]
 
 // Returns the hit slot (0..3) or -(victim+1): victim = first slot with the smallest timestamp (sketch.cpp:190-191).
-__device__ inline int lru_find(const LruBucket &b, uint32_t x) {
+__device__ inline int lru_find(const LruR &b, uint32_t x) {
+    const int hit = find_slot(b, x);
+    if (hit >= 0) return hit;
     int victim = -1, t_min = 1000000000;
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i) {
-        if ((uint32_t)b.val[i] == x) return i;
-        if (t_min > b.t[i]) { t_min = b.t[i]; victim = i; }
-    }
+    if (t_min > b.t0) { t_min = b.t0; victim = 0; }
+    if (t_min > b.t1) { t_min = b.t1; victim = 1; }
+    if (t_min > b.t2) { t_min = b.t2; victim = 2; }
+    if (t_min > b.t3) { t_min = b.t3; victim = 3; }
     if (victim < 0) victim = 0;
     return -(victim + 1);
 }
 
 // sketch.cpp:165-188.  Returns the provisional ins[i]; cleared by the caller if a kind-1 move returns 0.
 template <class C>
-__device__ inline int lru_hit(LruBucket &b, int slot, float c, float thr, C &ctx, MoveReq &mv) {
+__device__ inline int lru_hit(LruR &b, int i, float c, float thr, C &ctx, MoveReq &mv) {
     int got = 0;
     mv.kind = 0;
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i) {
-        if (i == slot) {
-            b.t[i] = ctx.tick();
-            b.cnt[i] += c;
-            float now = b.cnt[i];
-            if (now >= thr && now - c < thr) ctx.crossed();
-            if (now >= thr && ctx.can_pop() && !b.dic[i]) { b.dic[i] = ctx.pop(); got = 1; }
-            if (now >= thr) {
-                mv.kind = 1; mv.x = (uint32_t)b.val[i]; mv.cnt = now; mv.dic = b.dic[i];
-                b.val[i] = 0; b.t[i] = 0; b.cnt[i] = 0; b.dic[i] = 0;
-            }
-        }
+    const int32_t t = ctx.tick();
+    const float now = sel4f(b.c0, b.c1, b.c2, b.c3, i) + c;
+    int32_t dic = sel4(b.d0, b.d1, b.d2, b.d3, i);
+    int32_t val = sel4(b.v0, b.v1, b.v2, b.v3, i);
+    float keep = now;
+    int32_t tt = t;
+    if (now >= thr && now - c < thr) ctx.crossed();
+    if (now >= thr && ctx.can_pop() && !dic) { dic = ctx.pop(); got = 1; }
+    if (now >= thr) {
+        mv.kind = 1; mv.x = (uint32_t)val; mv.cnt = now; mv.dic = dic;
+        val = 0; tt = 0; keep = 0.0f; dic = 0;
     }
+    CAFE_SET4(b.v0, b.v1, b.v2, b.v3, i, val);
+    CAFE_SET4(b.t0, b.t1, b.t2, b.t3, i, tt);
+    CAFE_SET4(b.c0, b.c1, b.c2, b.c3, i, keep);
+    CAFE_SET4(b.d0, b.d1, b.d2, b.d3, i, dic);
     return got;
 }
 
 // sketch.cpp:193-195: the evicted entry is moved to the main table if it is hot or has score >= 5.
-__device__ inline void lru_evict(const LruBucket &b, int victim, MoveReq &mv) {
+__device__ inline void lru_evict(const LruR &b, int victim, MoveReq &mv) {
     mv.kind = 0;
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i)
-        if (i == victim && (b.dic[i] || b.cnt[i] >= 5.0f)) {
-            mv.kind = 2; mv.x = (uint32_t)b.val[i]; mv.cnt = b.cnt[i]; mv.dic = b.dic[i];
-        }
+    const int32_t dic = sel4(b.d0, b.d1, b.d2, b.d3, victim);
+    const float cnt = sel4f(b.c0, b.c1, b.c2, b.c3, victim);
+    if (dic || cnt >= 5.0f) {
+        mv.kind = 2; mv.x = (uint32_t)sel4(b.v0, b.v1, b.v2, b.v3, victim); mv.cnt = cnt; mv.dic = dic;
+    }
 }
 
 // sketch.cpp:196-209.  Returns ins[i].
 template <class C>
-__device__ inline int lru_place(LruBucket &b, int victim, uint32_t x, float c, float thr, C &ctx) {
+__device__ inline int lru_place(LruR &b, int victim, uint32_t x, float c, float thr, C &ctx) {
     int got = 0;
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i) {
-        if (i == victim) {
-            b.val[i] = (int32_t)x;
-            b.t[i] = ctx.tick();
-            b.cnt[i] = 1.0f;                  // not c: sketch.cpp:198
-            b.dic[i] = 0;
-            if (1.0f >= thr && 1.0f - c < thr) ctx.crossed();
-            if (1.0f >= thr && ctx.can_pop()) { b.dic[i] = ctx.pop(); got = 1; }
-        }
-    }
+    const int32_t t = ctx.tick();
+    int32_t dic = 0;
+    if (1.0f >= thr && 1.0f - c < thr) ctx.crossed();
+    if (1.0f >= thr && ctx.can_pop()) { dic = ctx.pop(); got = 1; }
+    CAFE_SET4(b.v0, b.v1, b.v2, b.v3, victim, (int32_t)x);
+    CAFE_SET4(b.t0, b.t1, b.t2, b.t3, victim, t);
+    CAFE_SET4(b.c0, b.c1, b.c2, b.c3, victim, 1.0f);          // not c: sketch.cpp:198
+    CAFE_SET4(b.d0, b.d1, b.d2, b.d3, victim, dic);
     return got;
 }
 

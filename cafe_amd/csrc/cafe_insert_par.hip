@@ -32,8 +32,12 @@
 namespace cafe {
 
 constexpr int kThreads = 256;
-constexpr int kCap = 4096;        // items (probes + moves) a main owner sorts in LDS; items of an LRU owner
-constexpr int kCapEv = 512;       // moves one main partition can receive per round
+constexpr int kCapSmall = 1024;   // items an owner of a normal partition sorts in LDS (several workgroups per CU)
+constexpr int kCapBig = 8192;     // ... of a partition that holds a heavy id (one workgroup per CU)
+constexpr int kCapEv = 256;       // moves one main partition can receive per round
+constexpr int kTargetItems = 128; // average items per partition
+constexpr int kMaxBins = 8192;    // partitions per table (LDS histogram of k_assign)
+constexpr int kAssignChunk = 8192;
 constexpr int kMaxRounds = 16;
 constexpr int kScanBlock = 1024;
 
@@ -57,7 +61,6 @@ struct EvRes {              // outcome of a move, written by the main owner that
 };
 
 struct Ctl {                // zeroed at the start of every call
-    uint32_t count_m[2], count_l[2];
     uint32_t changed[kMaxRounds + 2];
     uint32_t overflow;
     uint32_t final_round;
@@ -66,10 +69,9 @@ struct Ctl {                // zeroed at the start of every call
 };
 
 struct ParWorkspace {
-    DevBuf ctl, cnt1, off1, rank1, items1, lcnt, linbox, evcnt, ev, evres, miss, outm, outl, stage_m, stage_l;
+    DevBuf ctl, cnt, off, rank, items, evcnt, ev, evres, miss, outm, outl, stage_m, stage_l, stage_tot, hadev;
     DevBuf flags, blocksum, ranks;
     void *evres_seen = nullptr;
-    int P1 = 0, P2 = 0;
     unsigned long long call_seq = 0;
 };
 
@@ -81,22 +83,6 @@ struct Geo {
 // ------------------------------------------------------------------------------------------------
 // small block-wide helpers
 // ------------------------------------------------------------------------------------------------
-__device__ inline int block_excl_scan(int v, int *sh /* kThreads + 1 */, int &total) {
-    const int t = threadIdx.x;
-    sh[t] = v;
-    __syncthreads();
-    for (int o = 1; o < kThreads; o <<= 1) {
-        int add = t >= o ? sh[t - o] : 0;
-        __syncthreads();
-        sh[t] += add;
-        __syncthreads();
-    }
-    total = sh[kThreads - 1];
-    int r = sh[t] - v;
-    __syncthreads();
-    return r;
-}
-
 // in-LDS bitonic sort of `len` (power of two) 64-bit keys
 __device__ inline void bitonic_sort(unsigned long long *key, int len) {
     for (int k = 2; k <= len; k <<= 1) {
@@ -120,51 +106,77 @@ __device__ inline int next_pow2(int v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// partition the batch by main-bucket owner
+// partition the batch by main-bucket owner and by LRU-bucket owner (both static for the call).
+// Ranks inside a partition come from LDS atomics per 8192-item chunk plus one global atomic per
+// (chunk, non-empty partition); the order inside a partition is arbitrary, owners sort by position.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_assign(Geo g, const int32_t *__restrict__ ids, uint32_t *__restrict__ cnt1, uint32_t *__restrict__ rank1) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.n) return;
-    int p = fast_hash((uint32_t)ids[i], g.fm1) / g.bpp1;
-    rank1[i] = atomicAdd(&cnt1[p], 1u);
+__global__ void __launch_bounds__(1024) k_assign(Geo g, const int32_t *__restrict__ ids, uint32_t *__restrict__ cnt /* [P1+P2] */,
+                                                 uint32_t *__restrict__ rank1, uint32_t *__restrict__ rank2) {
+    extern __shared__ uint32_t hist[];          // [P1 + P2]
+    uint32_t *h1 = hist, *h2 = hist + g.P1;
+    for (int b = threadIdx.x; b < g.P1 + g.P2; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const int begin = blockIdx.x * kAssignChunk, end = min(begin + kAssignChunk, g.n);
+    for (int i = begin + threadIdx.x; i < end; i += blockDim.x) {
+        uint32_t x = (uint32_t)ids[i];
+        rank1[i] = atomicAdd(&h1[fast_hash(x, g.fm1) / g.bpp1], 1u);
+        rank2[i] = atomicAdd(&h2[fast_hash(x, g.fm2) / g.bpp2], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < g.P1 + g.P2; b += blockDim.x) {
+        uint32_t c = hist[b];
+        if (c) hist[b] = atomicAdd(&cnt[b], c);
+    }
+    __syncthreads();
+    for (int i = begin + threadIdx.x; i < end; i += blockDim.x) {
+        uint32_t x = (uint32_t)ids[i];
+        rank1[i] += h1[fast_hash(x, g.fm1) / g.bpp1];
+        rank2[i] += h2[fast_hash(x, g.fm2) / g.bpp2];
+    }
 }
 
-__global__ void __launch_bounds__(1024) k_offsets(Geo g, const uint32_t *__restrict__ cnt1, uint32_t *__restrict__ off1,
+// block 0: offsets of the main partitions, block 1: of the LRU partitions
+__global__ void __launch_bounds__(1024) k_offsets(Geo g, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off,
                                                   Ctl *ctl, const DevState *st) {
     __shared__ uint32_t sh[1024];
     __shared__ uint32_t carry;
+    const int P = blockIdx.x == 0 ? g.P1 : g.P2;
+    const uint32_t *c = blockIdx.x == 0 ? cnt : cnt + g.P1;
+    uint32_t *o = blockIdx.x == 0 ? off : off + g.P1 + 1;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     uint32_t over = 0;
-    for (int base = 0; base < g.P1; base += 1024) {
+    for (int base = 0; base < P; base += 1024) {
         int i = base + threadIdx.x;
-        uint32_t v = i < g.P1 ? cnt1[i] : 0u;
-        if (v > (uint32_t)kCap) over = 1;
+        uint32_t v = i < P ? c[i] : 0u;
+        if (v > (uint32_t)kCapBig) over = 1;
         sh[threadIdx.x] = v;
         __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            uint32_t add = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+        for (int d = 1; d < 1024; d <<= 1) {
+            uint32_t add = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0u;
             __syncthreads();
             sh[threadIdx.x] += add;
             __syncthreads();
         }
-        if (i < g.P1) off1[i] = carry + sh[threadIdx.x] - v;
+        if (i < P) o[i] = carry + sh[threadIdx.x] - v;
         __syncthreads();
         if (threadIdx.x == 1023) carry += sh[1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) off1[g.P1] = carry;
+    if (threadIdx.x == 0) o[P] = carry;
     if (over) ctl->overflow = 1;
     // the LRU clock placeholder clock0 + 1 + position must stay a positive int
     if (threadIdx.x == 0 && (long long)st->clk + g.n + 2 >= 0x7fffffffLL) ctl->overflow = 1;
 }
 
-__global__ void k_scatter(Geo g, const int32_t *__restrict__ ids, const uint32_t *__restrict__ off1,
-                          const uint32_t *__restrict__ rank1, uint32_t *__restrict__ items1) {
+__global__ void k_scatter(Geo g, const int32_t *__restrict__ ids, const uint32_t *__restrict__ off,
+                          const uint32_t *__restrict__ rank1, const uint32_t *__restrict__ rank2,
+                          uint32_t *__restrict__ items1, uint32_t *__restrict__ items2) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.n) return;
-    int p = fast_hash((uint32_t)ids[i], g.fm1) / g.bpp1;
-    items1[off1[p] + rank1[i]] = (uint32_t)i;
+    const uint32_t x = (uint32_t)ids[i];
+    items1[off[fast_hash(x, g.fm1) / g.bpp1] + rank1[i]] = (uint32_t)i;
+    items2[off[g.P1 + 1 + fast_hash(x, g.fm2) / g.bpp2] + rank2[i]] = (uint32_t)i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -182,68 +194,38 @@ struct MainCtx {
     __device__ void crossed() { flags |= oCross; }
 };
 
-__device__ inline void load_main_r(MainBucket &b, const MainBucket *src) {
-    const int4 *p = reinterpret_cast<const int4 *>(src);
-    int4 v = p[0], d = p[1], c = p[2];
-    b.val[0] = v.x; b.val[1] = v.y; b.val[2] = v.z; b.val[3] = v.w;
-    b.dic[0] = d.x; b.dic[1] = d.y; b.dic[2] = d.z; b.dic[3] = d.w;
-    b.cnt[0] = __int_as_float(c.x); b.cnt[1] = __int_as_float(c.y); b.cnt[2] = __int_as_float(c.z); b.cnt[3] = __int_as_float(c.w);
-    b.flip = src->flip;
-}
-__device__ inline void store_main_r(MainBucket *dst, const MainBucket &b, uint32_t tag) {
-    int4 *p = reinterpret_cast<int4 *>(dst);
-    p[0] = make_int4(b.val[0], b.val[1], b.val[2], b.val[3]);
-    p[1] = make_int4(b.dic[0], b.dic[1], b.dic[2], b.dic[3]);
-    p[2] = make_int4(__float_as_int(b.cnt[0]), __float_as_int(b.cnt[1]), __float_as_int(b.cnt[2]), __float_as_int(b.cnt[3]));
-    p[3] = make_int4((int)b.flip, (int)tag, 0, 0);
-}
-__device__ inline void load_lru_r(LruBucket &b, const LruBucket *src) {
-    const int4 *p = reinterpret_cast<const int4 *>(src);
-    int4 v = p[0], d = p[1], c = p[2], t = p[3];
-    b.val[0] = v.x; b.val[1] = v.y; b.val[2] = v.z; b.val[3] = v.w;
-    b.dic[0] = d.x; b.dic[1] = d.y; b.dic[2] = d.z; b.dic[3] = d.w;
-    b.cnt[0] = __int_as_float(c.x); b.cnt[1] = __int_as_float(c.y); b.cnt[2] = __int_as_float(c.z); b.cnt[3] = __int_as_float(c.w);
-    b.t[0] = t.x; b.t[1] = t.y; b.t[2] = t.z; b.t[3] = t.w;
-    b.flip = src->flip;
-}
-__device__ inline void store_lru_r(LruBucket *dst, const LruBucket &b, uint32_t tag) {
-    int4 *p = reinterpret_cast<int4 *>(dst);
-    p[0] = make_int4(b.val[0], b.val[1], b.val[2], b.val[3]);
-    p[1] = make_int4(b.dic[0], b.dic[1], b.dic[2], b.dic[3]);
-    p[2] = make_int4(__float_as_int(b.cnt[0]), __float_as_int(b.cnt[1]), __float_as_int(b.cnt[2]), __float_as_int(b.cnt[3]));
-    p[3] = make_int4(b.t[0], b.t[1], b.t[2], b.t[3]);
-    p[4] = make_int4((int)b.flip, (int)tag, 0, 0);
-}
-
+// Staged buckets have a static home: the entry of a bucket is the sorted position of its first item inside its
+// partition's region, so a partition that is not re-run in a later round keeps its staged result.
 // key layout of a main owner: [bucket in partition : 25][2*position + phase : 23][move index | kind<<15 : 16]
+template <int CAP, bool BIG>
 __global__ void __launch_bounds__(kThreads) k_main_round(
     Geo g, int round, unsigned long long call_tag, const MainBucket *__restrict__ mt, const DevState *__restrict__ st,
-    Ctl *ctl, const int32_t *__restrict__ ids, const float *__restrict__ scores, const uint32_t *__restrict__ off1,
-    const uint32_t *__restrict__ items1, uint32_t *lcnt /* [2][P2] */, uint32_t *__restrict__ linbox,
-    const uint32_t *__restrict__ evcnt /* [2][P1] */, const MoveEv *__restrict__ ev, EvRes *__restrict__ evres,
-    uint8_t *__restrict__ miss, uint8_t *__restrict__ outm, MainBucket *__restrict__ stage_m) {
-    __shared__ unsigned long long key[kCap];
-    __shared__ uint32_t px[kCap];
-    __shared__ float pc[kCap];
-    __shared__ int32_t pd[kCap];
-    __shared__ int sh[kThreads + 1];
-    __shared__ uint32_t stage_base;
+    Ctl *ctl, const int32_t *__restrict__ ids, const float *__restrict__ scores, const uint32_t *__restrict__ off,
+    const uint32_t *__restrict__ items1, const uint32_t *__restrict__ evcnt /* [2][P1] */, const MoveEv *__restrict__ ev,
+    EvRes *__restrict__ evres, uint8_t *__restrict__ miss, uint8_t *__restrict__ outm, MainBucket *__restrict__ stage_m,
+    uint32_t *__restrict__ stage_tot, uint8_t *__restrict__ hadev) {
+    __shared__ unsigned long long key[CAP];
+    __shared__ uint32_t px[CAP];
+    __shared__ float pc[CAP];
+    __shared__ uint8_t po[CAP];
 
     if (ctl->final_round || st->fallback || ctl->overflow) return;
     const int p = blockIdx.x, tid = threadIdx.x;
-    const int par = round & 1, nxt = par ^ 1;
-    // housekeeping for the next round's counters (nobody reads or writes them during this kernel)
-    for (int q = p; q < g.P2; q += gridDim.x) if (tid == 0) lcnt[nxt * g.P2 + q] = 0;
-    if (p == 0 && tid == 0) ctl->count_m[nxt] = 0;
-
-    const uint32_t o0 = off1[p];
-    const int np = (int)(off1[p + 1] - o0);
-    const int ne = round > 1 ? (int)min(evcnt[nxt * g.P1 + p], (uint32_t)kCapEv) : 0;   // moves of round-1
+    const int prev = (round & 1) ^ 1;
+    const uint32_t o0 = off[p];
+    const int np = (int)(off[p + 1] - o0);
+    const uint32_t ne_raw = round > 1 ? evcnt[prev * g.P1 + p] : 0u;       // moves emitted by LRU round-1
+    if (ne_raw > (uint32_t)kCapEv) { if (tid == 0) ctl->overflow = 1; return; }
+    const int ne = (int)ne_raw;
     const int total = np + ne;
+    if (BIG ? (total <= kCapSmall) : (total > kCapSmall)) return;           // the other size class owns it
+    if (total > CAP) { if (tid == 0) ctl->overflow = 1; return; }
+    if (round > 1 && ne == 0 && !hadev[p]) return;        // same inputs as last round: staged result stands
+    if (tid == 0) { hadev[p] = ne > 0; stage_tot[p] = (uint32_t)total; }
     if (total == 0) return;
-    if (total > kCap) { if (tid == 0) ctl->overflow = 1; return; }
     const int len = next_pow2(total);
     const int b0 = p * g.bpp1;
+    const size_t evbase = (size_t)p * kCapEv;
 
     for (int j = tid; j < len; j += kThreads) {
         unsigned long long k = ~0ull;
@@ -253,7 +235,7 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
             k = ((unsigned long long)bl << 39) | ((unsigned long long)(2u * i) << 16);
         } else if (j < total) {
             int e = j - np;
-            const MoveEv &m = ev[(size_t)p * kCapEv + e];
+            const MoveEv &m = ev[evbase + e];
             uint32_t bl = (uint32_t)(fast_hash(m.x, g.fm1) - b0);
             k = ((unsigned long long)bl << 39) | ((unsigned long long)m.time << 16) | (unsigned)(e | ((m.kind == 1) << 15));
         }
@@ -265,63 +247,63 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
         unsigned long long k = key[s];
         uint32_t time = (uint32_t)(k >> 16) & 0x7fffffu;
         if (time & 1u) {
-            const MoveEv &m = ev[(size_t)p * kCapEv + (int)(k & 0x7fffu)];
-            px[s] = m.x; pc[s] = m.cnt; pd[s] = m.dic;
+            const MoveEv &m = ev[evbase + (int)(k & 0x7fffu)];
+            px[s] = m.x; pc[s] = m.cnt; po[s] = 0;
         } else {
             uint32_t i = time >> 1;
-            px[s] = (uint32_t)ids[i]; pc[s] = scores ? scores[i] : 1.0f; pd[s] = 0;
+            px[s] = (uint32_t)ids[i]; pc[s] = scores ? scores[i] : 1.0f;
+            po[s] = round > 1 ? miss[i] : 0;
         }
     }
-    // reserve staging room: one entry per distinct bucket
-    int heads = 0;
-    for (int s = tid; s < total; s += kThreads)
-        heads += (s == 0 || (key[s - 1] >> 39) != (key[s] >> 39)) ? 1 : 0;
-    int tot_heads;
-    int my = block_excl_scan(heads, sh, tot_heads);
-    if (tid == 0) stage_base = atomicAdd(&ctl->count_m[par], (uint32_t)tot_heads);
     __syncthreads();
-    uint32_t slot_out = stage_base + (uint32_t)my;
 
     const float thr = st->thr;
     const uint32_t gflip = (uint32_t)st->flip;
+    MainBucket *stage = stage_m + o0 + evbase;
     MainCtx ctx;
     ctx.full = st->fifo_len > 0;
-    int changed = 0, over = 0;
+    int changed = 0;
     for (int s = tid; s < total; s += kThreads) {
         const uint32_t bl = (uint32_t)(key[s] >> 39);
         if (s != 0 && (uint32_t)(key[s - 1] >> 39) == bl) continue;
-        MainBucket b;
-        load_main_r(b, &mt[b0 + (int)bl]);
+        MainR b;
+        load_main(b, &mt[b0 + (int)bl]);
         sync_flip(b, gflip);
         for (int e = s; e < total && (uint32_t)(key[e] >> 39) == bl; ++e) {
             const unsigned long long k = key[e];
             const uint32_t time = (uint32_t)(k >> 16) & 0x7fffffu;
-            const uint32_t pos = time >> 1;
             if (!(time & 1u)) {
-                ctx.pos = pos; ctx.flags = 0;
-                const uint32_t x = px[e];
-                int r = main_probe(b, x, pc[e], thr, ctx);
+                ctx.pos = time >> 1; ctx.flags = 0;
+                int r = main_probe(b, px[e], pc[e], thr, ctx);
                 const bool m = r < 0;
-                outm[pos] = (uint8_t)(ctx.flags | (m ? oMiss : 0) | (r > 0 ? oGot : 0));
-                if (round == 1 ? m : (m != (miss[pos] != 0))) changed = 1;
-                miss[pos] = m ? 1 : 0;
-                if (m) {
-                    int q = fast_hash(x, g.fm2) / g.bpp2;
-                    uint32_t at = atomicAdd(&lcnt[par * g.P2 + q], 1u);
-                    if (at < (uint32_t)kCap) linbox[(size_t)q * kCap + at] = pos; else over = 1;
-                }
+                if (m != (po[e] != 0)) changed = 1;
+                po[e] = (uint8_t)(ctx.flags | (m ? oMiss : 0) | (r > 0 ? oGot : 0));
             } else {
                 ctx.pushed = 0;
-                int ok = main_move(b, px[e], pc[e], pd[e], ctx);
+                const int32_t dic = ev[evbase + (int)(k & 0x7fffu)].dic;
+                int ok = main_move(b, px[e], pc[e], dic, ctx);
                 EvRes r;
-                r.tag = call_tag | (unsigned)round; r.kind = (int)((k >> 15) & 1u) ? 1 : 2; r.ok = ok; r.pushed = ctx.pushed; r.pad = 0;
-                evres[pos] = r;
+                r.tag = call_tag | (unsigned)round; r.kind = ((k >> 15) & 1u) ? 1 : 2; r.ok = ok; r.pushed = ctx.pushed; r.pad = 0;
+                evres[time >> 1] = r;
             }
         }
-        store_main_r(&stage_m[slot_out++], b, (uint32_t)(b0 + (int)bl));
+        store_main(&stage[s], b, b0 + (int)bl);
+    }
+    __syncthreads();
+    // parallel write-back of the per-item outcomes; entries that are not a bucket's first item are marked unused
+    for (int s = tid; s < total; s += kThreads) {
+        const unsigned long long k = key[s];
+        const uint32_t time = (uint32_t)(k >> 16) & 0x7fffffu;
+        if (!(time & 1u)) {
+            const uint32_t pos = time >> 1;
+            const uint8_t o = po[s];
+            outm[pos] = o;
+            miss[pos] = (o & oMiss) ? 1 : 0;
+        }
+        if (s != 0 && (uint32_t)(key[s - 1] >> 39) == (uint32_t)(k >> 39))
+            reinterpret_cast<int32_t *>(&stage[s])[13] = -1;         // tag word of store_main
     }
     if (changed) atomicOr(&ctl->changed[round], 1u);
-    if (over) ctl->overflow = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,57 +321,63 @@ struct LruCtx {
     __device__ void crossed() { flags |= oCross; }
 };
 
+template <int CAP, bool BIG>
 __global__ void __launch_bounds__(kThreads) k_lru_round(
-    Geo g, int round, const LruBucket *__restrict__ lt, DevState *st, Ctl *ctl, const int32_t *__restrict__ ids,
-    const float *__restrict__ scores, const uint32_t *__restrict__ lcnt, const uint32_t *__restrict__ linbox,
-    uint32_t *evcnt, MoveEv *__restrict__ ev, uint8_t *__restrict__ outl, LruBucket *__restrict__ stage_l) {
-    __shared__ unsigned long long key[kCap];
-    __shared__ uint32_t px[kCap];
-    __shared__ float pc[kCap];
-    __shared__ int sh[kThreads + 1];
-    __shared__ uint32_t stage_base;
+    Geo g, int round, const LruBucket *__restrict__ lt, const DevState *__restrict__ st, Ctl *ctl,
+    const int32_t *__restrict__ ids, const float *__restrict__ scores, const uint32_t *__restrict__ off,
+    const uint32_t *__restrict__ items2, const uint8_t *__restrict__ miss, uint32_t *evcnt, MoveEv *__restrict__ ev,
+    uint8_t *__restrict__ outl, LruBucket *__restrict__ stage_l, uint32_t *__restrict__ stage_tot) {
+    __shared__ unsigned long long key[CAP];
+    __shared__ uint32_t px[CAP];
+    __shared__ float pc[CAP];
+    __shared__ uint8_t po[CAP];
+    __shared__ int n_miss;
 
     if (ctl->final_round || st->fallback || ctl->overflow) return;
     const int q = blockIdx.x, tid = threadIdx.x;
     const int par = round & 1, nxt = par ^ 1;
     if (!ctl->changed[round]) {                    // the miss set repeated: the previous round is the answer
-        if (q == 0 && tid == 0) { ctl->final_round = (uint32_t)round; }
+        if (!BIG && q == 0 && tid == 0) ctl->final_round = (uint32_t)round;
         return;
     }
-    for (int p = q; p < g.P1; p += gridDim.x) if (tid == 0) evcnt[nxt * g.P1 + p] = 0;
-    if (q == 0 && tid == 0) ctl->count_l[nxt] = 0;
+    if (!BIG) for (int p = q; p < g.P1; p += gridDim.x) if (tid == 0) evcnt[nxt * g.P1 + p] = 0;
 
-    const int total = (int)lcnt[par * g.P2 + q];
-    if (total == 0) return;
-    if (total > kCap) { if (tid == 0) ctl->overflow = 1; return; }
-    const int len = next_pow2(total);
+    const uint32_t o0 = off[g.P1 + 1 + q];
+    const int cnt = (int)(off[g.P1 + 1 + q + 1] - o0);
+    if (BIG ? (cnt <= kCapSmall) : (cnt > kCapSmall)) return;
+    if (cnt > CAP) { if (tid == 0) ctl->overflow = 1; return; }
+    if (tid == 0) n_miss = 0;
+    __syncthreads();
+    const int len0 = next_pow2(cnt);
     const int b0 = q * g.bpp2;
-    for (int j = tid; j < len; j += kThreads) {
+    int mine = 0;
+    for (int j = tid; j < len0; j += kThreads) {
         unsigned long long k = ~0ull;
-        if (j < total) {
-            uint32_t i = linbox[(size_t)q * kCap + j];
-            uint32_t bl = (uint32_t)(fast_hash((uint32_t)ids[i], g.fm2) - b0);
-            k = ((unsigned long long)bl << 32) | i;
+        if (j < cnt) {
+            uint32_t i = items2[o0 + j];
+            if (miss[i]) {
+                uint32_t bl = (uint32_t)(fast_hash((uint32_t)ids[i], g.fm2) - b0);
+                k = ((unsigned long long)bl << 32) | i;
+                ++mine;
+            }
         }
         key[j] = k;
     }
+    if (mine) atomicAdd(&n_miss, mine);
     __syncthreads();
-    bitonic_sort(key, len);
+    const int total = n_miss;
+    if (tid == 0) stage_tot[g.P1 + q] = (uint32_t)total;
+    if (total == 0) return;
+    bitonic_sort(key, len0);
     for (int s = tid; s < total; s += kThreads) {
         uint32_t i = (uint32_t)key[s];
         px[s] = (uint32_t)ids[i]; pc[s] = scores ? scores[i] : 1.0f;
     }
-    int heads = 0;
-    for (int s = tid; s < total; s += kThreads)
-        heads += (s == 0 || (key[s - 1] >> 32) != (key[s] >> 32)) ? 1 : 0;
-    int tot_heads;
-    int my = block_excl_scan(heads, sh, tot_heads);
-    if (tid == 0) stage_base = atomicAdd(&ctl->count_l[par], (uint32_t)tot_heads);
     __syncthreads();
-    uint32_t slot_out = stage_base + (uint32_t)my;
 
     const float thr = st->thr;
     const uint32_t gflip = (uint32_t)st->flip;
+    LruBucket *stage = stage_l + o0;
     LruCtx ctx;
     ctx.full = st->fifo_len > 0;
     ctx.clk0 = st->clk;
@@ -397,8 +385,8 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
     for (int s = tid; s < total; s += kThreads) {
         const uint32_t bl = (uint32_t)(key[s] >> 32);
         if (s != 0 && (uint32_t)(key[s - 1] >> 32) == bl) continue;
-        LruBucket b;
-        load_lru_r(b, &lt[b0 + (int)bl]);
+        LruR b;
+        load_lru(b, &lt[b0 + (int)bl]);
         sync_flip(b, gflip);
         for (int e = s; e < total && (uint32_t)(key[e] >> 32) == bl; ++e) {
             const uint32_t pos = (uint32_t)key[e];
@@ -413,7 +401,7 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
                 lru_evict(b, -f - 1, mv);
                 got = lru_place(b, -f - 1, x, c, thr, ctx);
             }
-            outl[pos] = (uint8_t)(ctx.flags | (got ? oGot : 0));
+            po[e] = (uint8_t)(ctx.flags | (got ? oGot : 0));
             if (mv.kind) {
                 int p = fast_hash(mv.x, g.fm1) / g.bpp1;
                 uint32_t at = atomicAdd(&evcnt[par * g.P1 + p], 1u);
@@ -427,7 +415,13 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
                 }
             }
         }
-        store_lru_r(&stage_l[slot_out++], b, (uint32_t)(b0 + (int)bl));
+        store_lru(&stage[s], b, b0 + (int)bl);
+    }
+    __syncthreads();
+    for (int s = tid; s < total; s += kThreads) {
+        outl[(uint32_t)key[s]] = po[s];
+        if (s != 0 && (uint32_t)(key[s - 1] >> 32) == (uint32_t)(key[s] >> 32))
+            reinterpret_cast<int32_t *>(&stage[s])[17] = -1;         // tag word of store_lru
     }
     if (over) ctl->overflow = 1;
 }
@@ -482,30 +476,34 @@ __global__ void __launch_bounds__(kScanBlock) k_finish_flags(
     }
 }
 
-// one workgroup: totals, the free-list check, decision
-__global__ void __launch_bounds__(1024) k_finish_decide(Geo g, int nblocks, DevState *st, Ctl *ctl, uint32_t *blocksum) {
-    __shared__ unsigned long long tot[4];
-    if (threadIdx.x < 4) tot[threadIdx.x] = 0;
-    __syncthreads();
-    // exclusive scan of the block sums, in place, by one thread per counter (few hundred blocks)
-    if (threadIdx.x < 4) {
-        unsigned long long run = 0;
-        for (int b = 0; b < nblocks; ++b) {
-            uint32_t v = blocksum[b * 4 + threadIdx.x];
-            blocksum[b * 4 + threadIdx.x] = (uint32_t)run;
-            run += v;
+// one workgroup: exclusive scan of the per-block sums (in place), totals, the free-list check, decision
+__global__ void __launch_bounds__(256) k_finish_decide(Geo g, int nblocks, DevState *st, Ctl *ctl, uint32_t *blocksum) {
+    __shared__ unsigned long long wtot[4][4];
+    __shared__ unsigned long long carry[4];
+    const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;      // one wave per counter
+    unsigned long long run = 0;                                   // identical in every lane of the wave
+    for (int base = 0; base < nblocks; base += 64) {
+        const int b = base + lane;
+        uint32_t v = b < nblocks ? blocksum[b * 4 + c] : 0u;
+        uint32_t incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
         }
-        tot[threadIdx.x] = run;
+        if (b < nblocks) blocksum[b * 4 + c] = (uint32_t)run + incl - v;
+        run += __shfl(incl, 63, 64);
     }
+    if (lane == 0) carry[c] = run;
     __syncthreads();
+    (void)wtot;
     if (threadIdx.x == 0) {
         bool ok = !(st->fallback || ctl->overflow) && ctl->final_round != 0;
         if (ok) {
-            if (st->fifo_len > 0) ok = tot[0] <= (unsigned long long)st->fifo_len;      // never ran dry
-            else ok = tot[1] == 0;                                                       // never refilled
+            if (st->fifo_len > 0) ok = carry[0] <= (unsigned long long)st->fifo_len;      // never ran dry
+            else ok = carry[1] == 0;                                                       // never refilled
         }
-        ctl->tot_pop = (uint32_t)tot[0]; ctl->tot_push = (uint32_t)tot[1]; ctl->tot_clk = (uint32_t)tot[2];
-        ctl->tot_cross = tot[3];
+        ctl->tot_pop = (uint32_t)carry[0]; ctl->tot_push = (uint32_t)carry[1]; ctl->tot_clk = (uint32_t)carry[2];
+        ctl->tot_cross = carry[3];
         st->rounds = (int32_t)ctl->final_round;
         if (!ok) st->fallback = 1;
     }
@@ -541,47 +539,58 @@ __device__ inline int32_t resolve_dic(int32_t d, const uint32_t *fifo, uint32_t 
     return d;
 }
 
-// commit: staged buckets -> tables with placeholders resolved; pushes -> free list
+// commit: staged buckets -> tables with placeholders resolved; pushes -> free list.
+// Workgroups walk the partitions' staging regions (main partitions, then LRU partitions), then the batch for pushes.
 __global__ void __launch_bounds__(256) k_commit(Geo g, MainBucket *mt, LruBucket *lt, uint32_t *fifo, uint32_t cap,
-                                                const DevState *st, const Ctl *ctl, const MainBucket *__restrict__ stage_m,
+                                                const DevState *st, const Ctl *ctl, const uint32_t *__restrict__ off,
+                                                const uint32_t *__restrict__ stage_tot, const MainBucket *__restrict__ stage_m,
                                                 const LruBucket *__restrict__ stage_l, const uint8_t *__restrict__ flags,
                                                 const int32_t *__restrict__ pushval, const uint32_t *__restrict__ poprank,
                                                 const uint32_t *__restrict__ pushrank, const uint32_t *__restrict__ clkrank) {
     if (st->fallback) return;
     const uint32_t head = st->fifo_head, len0 = st->fifo_len;
     const int32_t clk0 = st->clk;
-    const uint32_t fr = ctl->final_round;
-    const uint32_t nm = ctl->count_m[fr & 1];
-    const uint32_t nl = fr > 1 ? ctl->count_l[(fr - 1) & 1] : 0;
-    const long work = (long)nm + nl + g.n;
-    for (long w = (long)blockIdx.x * blockDim.x + threadIdx.x; w < work; w += (long)gridDim.x * blockDim.x) {
-        if (w < nm) {
-            const int4 *p = reinterpret_cast<const int4 *>(&stage_m[w]);
-            int4 v = p[0], d = p[1], c = p[2], m = p[3];
-            d.x = resolve_dic(d.x, fifo, cap, head, poprank); d.y = resolve_dic(d.y, fifo, cap, head, poprank);
-            d.z = resolve_dic(d.z, fifo, cap, head, poprank); d.w = resolve_dic(d.w, fifo, cap, head, poprank);
-            int4 *o = reinterpret_cast<int4 *>(&mt[m.y]);
-            o[0] = v; o[1] = d; o[2] = c;
-            mt[m.y].flip = (uint32_t)m.x;
-        } else if (w < (long)nm + nl) {
-            const int4 *p = reinterpret_cast<const int4 *>(&stage_l[w - nm]);
-            int4 v = p[0], d = p[1], c = p[2], t = p[3], m = p[4];
-            d.x = resolve_dic(d.x, fifo, cap, head, poprank); d.y = resolve_dic(d.y, fifo, cap, head, poprank);
-            d.z = resolve_dic(d.z, fifo, cap, head, poprank); d.w = resolve_dic(d.w, fifo, cap, head, poprank);
-            if (t.x > clk0) t.x = clk0 + 1 + (int32_t)clkrank[t.x - clk0 - 1];
-            if (t.y > clk0) t.y = clk0 + 1 + (int32_t)clkrank[t.y - clk0 - 1];
-            if (t.z > clk0) t.z = clk0 + 1 + (int32_t)clkrank[t.z - clk0 - 1];
-            if (t.w > clk0) t.w = clk0 + 1 + (int32_t)clkrank[t.w - clk0 - 1];
-            int4 *o = reinterpret_cast<int4 *>(&lt[m.y]);
-            o[0] = v; o[1] = d; o[2] = c; o[3] = t;
-            lt[m.y].flip = (uint32_t)m.x;
-        } else {
-            const long i = w - nm - nl;
-            if (flags[i] & 2) {
-                // pushes land behind everything the list held; pops only ever take what it held at the start
-                int32_t d = resolve_dic(pushval[i], fifo, cap, head, poprank);
-                fifo[(unsigned long long)((unsigned long long)head + len0 + pushrank[i]) % cap] = (uint32_t)d;
+    const int nparts = g.P1 + (ctl->final_round > 1 ? g.P2 : 0);      // round 1 final = nothing missed, no LRU work
+    for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
+        const int tot = (int)stage_tot[part];
+        if (part < g.P1) {
+            const MainBucket *stage = stage_m + off[part] + (size_t)part * kCapEv;
+            for (int s = threadIdx.x; s < tot; s += blockDim.x) {
+                const int4 *p = reinterpret_cast<const int4 *>(&stage[s]);
+                const int4 m = p[3];
+                if (m.y < 0) continue;
+                int4 v = p[0], d = p[1], c = p[2];
+                d.x = resolve_dic(d.x, fifo, cap, head, poprank); d.y = resolve_dic(d.y, fifo, cap, head, poprank);
+                d.z = resolve_dic(d.z, fifo, cap, head, poprank); d.w = resolve_dic(d.w, fifo, cap, head, poprank);
+                int4 *o = reinterpret_cast<int4 *>(&mt[m.y]);
+                o[0] = v; o[1] = d; o[2] = c;
+                mt[m.y].flip = (uint32_t)m.x;
             }
+        } else {
+            const LruBucket *stage = stage_l + off[g.P1 + 1 + (part - g.P1)];
+            for (int s = threadIdx.x; s < tot; s += blockDim.x) {
+                const int4 *p = reinterpret_cast<const int4 *>(&stage[s]);
+                const int4 m = p[4];
+                if (m.y < 0) continue;
+                int4 v = p[0], d = p[1], c = p[2], t = p[3];
+                d.x = resolve_dic(d.x, fifo, cap, head, poprank); d.y = resolve_dic(d.y, fifo, cap, head, poprank);
+                d.z = resolve_dic(d.z, fifo, cap, head, poprank); d.w = resolve_dic(d.w, fifo, cap, head, poprank);
+                if (t.x > clk0) t.x = clk0 + 1 + (int32_t)clkrank[t.x - clk0 - 1];
+                if (t.y > clk0) t.y = clk0 + 1 + (int32_t)clkrank[t.y - clk0 - 1];
+                if (t.z > clk0) t.z = clk0 + 1 + (int32_t)clkrank[t.z - clk0 - 1];
+                if (t.w > clk0) t.w = clk0 + 1 + (int32_t)clkrank[t.w - clk0 - 1];
+                int4 *o = reinterpret_cast<int4 *>(&lt[m.y]);
+                o[0] = v; o[1] = d; o[2] = c; o[3] = t;
+                lt[m.y].flip = (uint32_t)m.x;
+            }
+        }
+    }
+    if (ctl->tot_push == 0) return;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += (long)gridDim.x * blockDim.x) {
+        if (flags[i] & 2) {
+            // pushes land behind everything the list held; pops only ever take what it held at the start
+            int32_t d = resolve_dic(pushval[i], fifo, cap, head, poprank);
+            fifo[(unsigned long long)((unsigned long long)head + len0 + pushrank[i]) % cap] = (uint32_t)d;
         }
     }
 }
@@ -601,28 +610,29 @@ __global__ void k_commit_scalars(DevState *st, const Ctl *ctl, uint32_t cap) {
 // ------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------
+static void pick_parts(int n, int buckets, int &P, int &bpp) {
+    int want = std::max(1, (n + kTargetItems - 1) / kTargetItems);
+    P = std::min(std::min(want, buckets), kMaxBins);
+    bpp = (buckets + P - 1) / P;
+    P = (buckets + bpp - 1) / bpp;
+}
+
 static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     if (!s->par) s->par = new ParWorkspace();
     ParWorkspace &w = *s->par;
     g.n = n; g.n1 = s->n1; g.n2 = s->n2;
-    int want = std::max(1, (n + 511) / 512);
-    g.P1 = std::min(want, s->n1);
-    g.bpp1 = (s->n1 + g.P1 - 1) / g.P1;
-    g.P1 = (s->n1 + g.bpp1 - 1) / g.bpp1;
-    g.P2 = std::min(want, s->n2);
-    g.bpp2 = (s->n2 + g.P2 - 1) / g.P2;
-    g.P2 = (s->n2 + g.bpp2 - 1) / g.bpp2;
+    pick_parts(n, s->n1, g.P1, g.bpp1);
+    pick_parts(n, s->n2, g.P2, g.bpp2);
     g.fm1 = make_fastmod(s->n1);
     g.fm2 = make_fastmod(s->n2);
-    size_t N = (size_t)n;
-    int nblocks = (n + kScanBlock - 1) / kScanBlock;
-    if (w.ctl.reserve(sizeof(Ctl)) || w.cnt1.reserve(4 * (size_t)g.P1 + 4) || w.off1.reserve(4 * (size_t)g.P1 + 8) ||
-        w.rank1.reserve(4 * N) || w.items1.reserve(4 * N) || w.lcnt.reserve(8 * (size_t)g.P2) ||
-        w.linbox.reserve(4 * (size_t)g.P2 * kCap) || w.evcnt.reserve(8 * (size_t)g.P1) ||
-        w.ev.reserve(sizeof(MoveEv) * (size_t)g.P1 * kCapEv) || w.evres.reserve(sizeof(EvRes) * N) ||
-        w.miss.reserve(N) || w.outm.reserve(N) || w.outl.reserve(N) ||
+    const size_t N = (size_t)n, PP = (size_t)g.P1 + g.P2;
+    const int nblocks = (n + kScanBlock - 1) / kScanBlock;
+    if (w.ctl.reserve(sizeof(Ctl)) || w.cnt.reserve(4 * PP + 4) || w.off.reserve(4 * PP + 16) || w.rank.reserve(8 * N) ||
+        w.items.reserve(8 * N) || w.evcnt.reserve(8 * (size_t)g.P1) || w.ev.reserve(sizeof(MoveEv) * (size_t)g.P1 * kCapEv) ||
+        w.evres.reserve(sizeof(EvRes) * N) || w.miss.reserve(N) || w.outm.reserve(N) || w.outl.reserve(N) ||
         w.stage_m.reserve(sizeof(MainBucket) * (N + (size_t)g.P1 * kCapEv)) || w.stage_l.reserve(sizeof(LruBucket) * N) ||
-        w.flags.reserve(5 * N + 64) || w.blocksum.reserve(16 * (size_t)nblocks + 16) || w.ranks.reserve(12 * N))
+        w.stage_tot.reserve(4 * PP + 4) || w.hadev.reserve((size_t)g.P1 + 4) || w.flags.reserve(5 * N + 64) ||
+        w.blocksum.reserve(16 * (size_t)nblocks + 16) || w.ranks.reserve(12 * N))
         return 1;
     if (w.evres.p != w.evres_seen) {      // tags of a fresh allocation must not match by accident
         CAFE_HIP_CHECK(hipMemset(w.evres.p, 0, w.evres.cap));
@@ -633,10 +643,7 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
 
 int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st) {
     Geo g;
-    if (n > (1 << 21)) {     // the 23-bit time field of the sort key: split very large batches
-        int done = 0;
-        // a batch is one call in the reference; splitting would change decay/reset points, so use the in-order kernel
-        (void)done;
+    if (n > (1 << 21)) {     // the 23-bit time field of the owners' sort key
         s->counters[2]++;
         return launch_serial_insert(s, d_ids, d_scores, n, d_ins, 0, st);
     }
@@ -645,25 +652,35 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     w.call_seq++;
     const unsigned long long tag = w.call_seq << 8;
     Ctl *ctl = w.ctl.as<Ctl>();
+    uint32_t *cnt = w.cnt.as<uint32_t>(), *off = w.off.as<uint32_t>();
+    uint32_t *rank1 = w.rank.as<uint32_t>(), *rank2 = rank1 + n;
+    uint32_t *items1 = w.items.as<uint32_t>(), *items2 = items1 + n;
+    uint32_t *evcnt = w.evcnt.as<uint32_t>(), *stage_tot = w.stage_tot.as<uint32_t>();
     CAFE_HIP_CHECK(hipMemsetAsync(ctl, 0, sizeof(Ctl), st));
-    CAFE_HIP_CHECK(hipMemsetAsync(w.cnt1.p, 0, 4 * (size_t)g.P1, st));
-    CAFE_HIP_CHECK(hipMemsetAsync(w.lcnt.p, 0, 8 * (size_t)g.P2, st));
-    CAFE_HIP_CHECK(hipMemsetAsync(w.evcnt.p, 0, 8 * (size_t)g.P1, st));
+    CAFE_HIP_CHECK(hipMemsetAsync(cnt, 0, 4 * ((size_t)g.P1 + g.P2), st));
+    CAFE_HIP_CHECK(hipMemsetAsync(evcnt, 0, 8 * (size_t)g.P1, st));
     const int gb = (n + 255) / 256;
-    hipLaunchKernelGGL(k_assign, dim3(gb), dim3(256), 0, st, g, d_ids, w.cnt1.as<uint32_t>(), w.rank1.as<uint32_t>());
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, st, g, w.cnt1.as<uint32_t>(), w.off1.as<uint32_t>(), ctl, s->d_state);
-    hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, g, d_ids, w.off1.as<uint32_t>(), w.rank1.as<uint32_t>(),
-                       w.items1.as<uint32_t>());
+    hipLaunchKernelGGL(k_assign, dim3((n + kAssignChunk - 1) / kAssignChunk), dim3(1024), 4 * (size_t)(g.P1 + g.P2), st, g,
+                       d_ids, cnt, rank1, rank2);
+    hipLaunchKernelGGL(k_offsets, dim3(2), dim3(1024), 0, st, g, cnt, off, ctl, s->d_state);
+    hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, g, d_ids, off, rank1, rank2, items1, items2);
     const int rounds = std::min(std::max(s->opt_max_rounds, 1), kMaxRounds);
+#define CAFE_MAIN(CAPV, BIGV)                                                                                              \
+    hipLaunchKernelGGL((k_main_round<CAPV, BIGV>), dim3(g.P1), dim3(kThreads), 0, st, g, r, tag, s->d_main, s->d_state, ctl, \
+                       d_ids, d_scores, off, items1, evcnt, w.ev.as<MoveEv>(), w.evres.as<EvRes>(), w.miss.as<uint8_t>(),    \
+                       w.outm.as<uint8_t>(), w.stage_m.as<MainBucket>(), stage_tot, w.hadev.as<uint8_t>())
+#define CAFE_LRU(CAPV, BIGV)                                                                                               \
+    hipLaunchKernelGGL((k_lru_round<CAPV, BIGV>), dim3(g.P2), dim3(kThreads), 0, st, g, r, s->d_lru, s->d_state, ctl, d_ids, \
+                       d_scores, off, items2, w.miss.as<uint8_t>(), evcnt, w.ev.as<MoveEv>(), w.outl.as<uint8_t>(),          \
+                       w.stage_l.as<LruBucket>(), stage_tot)
     for (int r = 1; r <= rounds + 1; ++r) {
-        hipLaunchKernelGGL(k_main_round, dim3(g.P1), dim3(kThreads), 0, st, g, r, tag, s->d_main, s->d_state, ctl, d_ids,
-                           d_scores, w.off1.as<uint32_t>(), w.items1.as<uint32_t>(), w.lcnt.as<uint32_t>(),
-                           w.linbox.as<uint32_t>(), w.evcnt.as<uint32_t>(), w.ev.as<MoveEv>(), w.evres.as<EvRes>(),
-                           w.miss.as<uint8_t>(), w.outm.as<uint8_t>(), w.stage_m.as<MainBucket>());
-        hipLaunchKernelGGL(k_lru_round, dim3(g.P2), dim3(kThreads), 0, st, g, r, s->d_lru, s->d_state, ctl, d_ids, d_scores,
-                           w.lcnt.as<uint32_t>(), w.linbox.as<uint32_t>(), w.evcnt.as<uint32_t>(), w.ev.as<MoveEv>(),
-                           w.outl.as<uint8_t>(), w.stage_l.as<LruBucket>());
+        CAFE_MAIN(kCapSmall, false);
+        CAFE_MAIN(kCapBig, true);
+        CAFE_LRU(kCapSmall, false);
+        CAFE_LRU(kCapBig, true);
     }
+#undef CAFE_MAIN
+#undef CAFE_LRU
     const int nb = (n + kScanBlock - 1) / kScanBlock;
     uint8_t *flags = w.flags.as<uint8_t>();
     int32_t *pushval = (int32_t *)(flags + (((size_t)n + 15) & ~(size_t)15));
@@ -671,13 +688,13 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     hipLaunchKernelGGL(k_finish_flags, dim3(nb), dim3(kScanBlock), 0, st, g, tag, s->d_state, ctl, w.miss.as<uint8_t>(),
                        w.outm.as<uint8_t>(), w.outl.as<uint8_t>(), w.evres.as<EvRes>(), d_ins, flags, pushval,
                        w.blocksum.as<uint32_t>());
-    hipLaunchKernelGGL(k_finish_decide, dim3(1), dim3(1024), 0, st, g, nb, s->d_state, ctl, w.blocksum.as<uint32_t>());
+    hipLaunchKernelGGL(k_finish_decide, dim3(1), dim3(256), 0, st, g, nb, s->d_state, ctl, w.blocksum.as<uint32_t>());
     hipLaunchKernelGGL(k_finish_ranks, dim3(nb), dim3(kScanBlock), 0, st, g, s->d_state, flags, w.blocksum.as<uint32_t>(),
                        poprank, pushrank, clkrank);
-    const long work = (long)n * 2 + (long)g.P1 * kCapEv;
-    const int cb = (int)std::min<long>((work + 255) / 256, 2048);
+    const int cb = std::min(g.P1 + g.P2, 2048);
     hipLaunchKernelGGL(k_commit, dim3(cb), dim3(256), 0, st, g, s->d_main, s->d_lru, s->d_fifo, s->fifo_cap, s->d_state, ctl,
-                       w.stage_m.as<MainBucket>(), w.stage_l.as<LruBucket>(), flags, pushval, poprank, pushrank, clkrank);
+                       off, stage_tot, w.stage_m.as<MainBucket>(), w.stage_l.as<LruBucket>(), flags, pushval, poprank,
+                       pushrank, clkrank);
     hipLaunchKernelGGL(k_commit_scalars, dim3(1), dim3(64), 0, st, s->d_state, ctl, s->fifo_cap);
     CAFE_HIP_CHECK(hipGetLastError());
     // batches the owners could not settle run in order, from the untouched tables
@@ -689,8 +706,8 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
 void par_free(cafe_sketch *s) {
     if (!s->par) return;
     ParWorkspace &w = *s->par;
-    DevBuf *all[] = {&w.ctl, &w.cnt1, &w.off1, &w.rank1, &w.items1, &w.lcnt, &w.linbox, &w.evcnt, &w.ev, &w.evres, &w.miss,
-                     &w.outm, &w.outl, &w.stage_m, &w.stage_l, &w.flags, &w.blocksum, &w.ranks};
+    DevBuf *all[] = {&w.ctl, &w.cnt, &w.off, &w.rank, &w.items, &w.evcnt, &w.ev, &w.evres, &w.miss, &w.outm, &w.outl,
+                     &w.stage_m, &w.stage_l, &w.stage_tot, &w.hadev, &w.flags, &w.blocksum, &w.ranks};
     for (DevBuf *b : all) b->release();
     delete s->par;
     s->par = nullptr;

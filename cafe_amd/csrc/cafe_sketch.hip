@@ -141,39 +141,6 @@ struct SerialCtx {
     __device__ void crossed() { ++real_n; }
 };
 
-__device__ inline void store_main(MainBucket *dst, const MainBucket &b) {
-    int4 *p = reinterpret_cast<int4 *>(dst);
-    p[0] = make_int4(b.val[0], b.val[1], b.val[2], b.val[3]);
-    p[1] = make_int4(b.dic[0], b.dic[1], b.dic[2], b.dic[3]);
-    p[2] = make_int4(__float_as_int(b.cnt[0]), __float_as_int(b.cnt[1]), __float_as_int(b.cnt[2]), __float_as_int(b.cnt[3]));
-    dst->flip = b.flip;
-}
-__device__ inline void load_main(MainBucket &b, const MainBucket *src) {
-    const int4 *p = reinterpret_cast<const int4 *>(src);
-    int4 v = p[0], d = p[1], c = p[2];
-    b.val[0] = v.x; b.val[1] = v.y; b.val[2] = v.z; b.val[3] = v.w;
-    b.dic[0] = d.x; b.dic[1] = d.y; b.dic[2] = d.z; b.dic[3] = d.w;
-    b.cnt[0] = __int_as_float(c.x); b.cnt[1] = __int_as_float(c.y); b.cnt[2] = __int_as_float(c.z); b.cnt[3] = __int_as_float(c.w);
-    b.flip = src->flip;
-}
-__device__ inline void store_lru(LruBucket *dst, const LruBucket &b) {
-    int4 *p = reinterpret_cast<int4 *>(dst);
-    p[0] = make_int4(b.val[0], b.val[1], b.val[2], b.val[3]);
-    p[1] = make_int4(b.dic[0], b.dic[1], b.dic[2], b.dic[3]);
-    p[2] = make_int4(__float_as_int(b.cnt[0]), __float_as_int(b.cnt[1]), __float_as_int(b.cnt[2]), __float_as_int(b.cnt[3]));
-    p[3] = make_int4(b.t[0], b.t[1], b.t[2], b.t[3]);
-    dst->flip = b.flip;
-}
-__device__ inline void load_lru(LruBucket &b, const LruBucket *src) {
-    const int4 *p = reinterpret_cast<const int4 *>(src);
-    int4 v = p[0], d = p[1], c = p[2], t = p[3];
-    b.val[0] = v.x; b.val[1] = v.y; b.val[2] = v.z; b.val[3] = v.w;
-    b.dic[0] = d.x; b.dic[1] = d.y; b.dic[2] = d.z; b.dic[3] = d.w;
-    b.cnt[0] = __int_as_float(c.x); b.cnt[1] = __int_as_float(c.y); b.cnt[2] = __int_as_float(c.z); b.cnt[3] = __int_as_float(c.w);
-    b.t[0] = t.x; b.t[1] = t.y; b.t[2] = t.z; b.t[3] = t.w;
-    b.flip = src->flip;
-}
-
 __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket *lt, uint32_t *fifo, uint32_t cap,
                                                       DevState *st, int n1, int n2, const int32_t *__restrict__ ids,
                                                       const float *__restrict__ scores, int n, int32_t *__restrict__ ins,
@@ -189,14 +156,14 @@ __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket 
         uint32_t x = (uint32_t)ids[i];
         float c = scores ? scores[i] : 1.0f;
         int k = hash_main(x, n1);
-        MainBucket b;
+        MainR b;
         load_main(b, &mt[k]);
         sync_flip(b, gflip);
         int r = main_probe(b, x, c, thr, ctx);
         store_main(&mt[k], b);           // also persists the lazy decay on a miss (sketch.cpp:213)
         if (r >= 0) { ins[i] = r; continue; }
         int k2 = hash_lru(x, n2);
-        LruBucket l;
+        LruR l;
         load_lru(l, &lt[k2]);
         sync_flip(l, gflip);
         MoveReq mv;
@@ -208,7 +175,7 @@ __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket 
         }
         if (mv.kind) {
             int km = hash_main(mv.x, n1);
-            MainBucket m;
+            MainR m;
             load_main(m, &mt[km]);
             sync_flip(m, gflip);
             int ok = main_move(m, mv.x, mv.cnt, mv.dic, ctx);
@@ -252,25 +219,31 @@ __global__ void k_reset_collect(MainBucket *mt, LruBucket *lt, int n1, int n2, D
     const long total = (long)n1 + n2;
     for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
         if (g < n1) {
-            MainBucket b;
+            MainR b;
             load_main(b, &mt[g]);
             if (b.flip != gflip) { sync_flip(b, gflip); store_main(&mt[g], b); }
             uint32_t base = (lru_first ? (uint32_t)n2 * kSlots : 0u) + (uint32_t)g * kSlots;
+            const float cn[4] = {b.c0, b.c1, b.c2, b.c3};
+            const int32_t dc[4] = {b.d0, b.d1, b.d2, b.d3};
+#pragma unroll
             for (int i = 0; i < kSlots; ++i)
-                if (b.cnt[i] >= thr || b.dic[i]) {
+                if (cn[i] >= thr || dc[i]) {
                     unsigned int at = atomicAdd(count, 1u);
-                    keys[at] = ((unsigned long long)orderable(b.cnt[i]) << 32) | (base + i);
+                    keys[at] = ((unsigned long long)orderable(cn[i]) << 32) | (base + i);
                 }
         } else {
             long k = g - n1;
-            LruBucket b;
+            LruR b;
             load_lru(b, &lt[k]);
             if (b.flip != gflip) { sync_flip(b, gflip); store_lru(&lt[k], b); }
             uint32_t base = (lru_first ? 0u : (uint32_t)n1 * kSlots) + (uint32_t)k * kSlots;
+            const float cn[4] = {b.c0, b.c1, b.c2, b.c3};
+            const int32_t dc[4] = {b.d0, b.d1, b.d2, b.d3};
+#pragma unroll
             for (int i = 0; i < kSlots; ++i)
-                if (b.cnt[i] >= thr || b.dic[i]) {
+                if (cn[i] >= thr || dc[i]) {
                     unsigned int at = atomicAdd(count, 1u);
-                    keys[at] = ((unsigned long long)orderable(b.cnt[i]) << 32) | (base + i);
+                    keys[at] = ((unsigned long long)orderable(cn[i]) << 32) | (base + i);
                 }
         }
     }
