@@ -46,7 +46,7 @@ struct DevState {
     uint32_t fifo_head, fifo_len;
     int32_t flip, resets;
     // scratch written by kernels of the current call
-    int32_t need_reset, fallback, rounds, converged;
+    int32_t maxpart, fallback, rounds, converged;    // maxpart: largest partition of the last parallel insert
     int32_t pad[4];
 };
 

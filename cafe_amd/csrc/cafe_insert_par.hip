@@ -32,19 +32,22 @@
 namespace cafe {
 
 constexpr int kThreads = 256;
-constexpr int kCapSmall = 1024;   // items an owner of a normal partition sorts in LDS (several workgroups per CU)
+constexpr int kCapSmall = 2048;   // items an owner of a normal partition sorts in LDS (several workgroups per CU)
 constexpr int kCapBig = 8192;     // ... of a partition that holds a heavy id (one workgroup per CU)
 constexpr int kCapEv = 256;       // moves one main partition can receive per round
+constexpr int kCapEvL = 256;      // moves one LRU partition can emit per round
 constexpr int kTargetItems = 128; // average items per partition
 constexpr int kMaxBins = 8192;    // partitions per table (LDS histogram of k_assign)
 constexpr int kAssignChunk = 8192;
 constexpr int kMaxRounds = 16;
+constexpr int kHeavySeg = 32;     // a bucket with at least this many items in the batch is replayed by a whole wave
+constexpr int kMaxHeavy = 64;     // heavy buckets one partition can hand to its waves (more: replayed by single lanes)
 constexpr int kScanBlock = 1024;
 
 constexpr uint32_t kSur = 0x80000000u;      // placeholder for "slot popped by item (v & 0x7fffffff)"
 
 // outcome bits per item
-constexpr uint8_t oGot = 1, oPop = 2, oCross = 4, oMiss = 8;
+constexpr uint8_t oGot = 1, oPop = 2, oCross = 4, oMiss = 8, oEv = 16;   // oEv: the item's LRU step emitted a move
 
 struct MoveEv {             // a move into the main table emitted by an LRU owner
     uint32_t time;          // 2 * position + 1: after the item's own probe
@@ -56,7 +59,7 @@ struct MoveEv {             // a move into the main table emitted by an LRU owne
 };
 
 struct EvRes {              // outcome of a move, written by the main owner that carried it out
-    unsigned long long tag; // (call sequence << 8) | round
+    unsigned long long tag; // call sequence number
     int32_t kind, ok, pushed, pad;
 };
 
@@ -64,12 +67,14 @@ struct Ctl {                // zeroed at the start of every call
     uint32_t changed[kMaxRounds + 2];
     uint32_t overflow;
     uint32_t final_round;
-    unsigned long long tot_cross;
-    uint32_t tot_pop, tot_push, tot_clk, pad;
+    uint32_t maxpart;       // largest partition (items) of this call
+    uint32_t totals[8];     // pops, pushes, clock ticks, threshold crossings, rounds: applied by the closing kernel
 };
 
 struct ParWorkspace {
-    DevBuf ctl, cnt, off, rank, items, evcnt, ev, evres, miss, outm, outl, stage_m, stage_l, stage_tot, hadev;
+    DevBuf zr;              // [Ctl][cnt: P1+P2][evcnt: 2*P1], zeroed by the per-call prologue kernel
+    DevBuf off, rank, items, ev, evres, miss, outm, outl, stage_m, stage_l, stage_tot, prevcnt;
+    DevBuf ldirty, myev, mycnt;
     DevBuf flags, blocksum, ranks;
     void *evres_seen = nullptr;
     unsigned long long call_seq = 0;
@@ -79,6 +84,7 @@ struct Geo {
     int n, n1, n2, P1, P2, bpp1, bpp2;
     FastMod fm1, fm2;
 };
+constexpr size_t kCtlWords = (sizeof(Ctl) + 3) / 4;
 
 // ------------------------------------------------------------------------------------------------
 // small block-wide helpers
@@ -145,11 +151,12 @@ __global__ void __launch_bounds__(1024) k_offsets(Geo g, const uint32_t *__restr
     uint32_t *o = blockIdx.x == 0 ? off : off + g.P1 + 1;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    uint32_t over = 0;
+    uint32_t over = 0, vmax = 0;
     for (int base = 0; base < P; base += 1024) {
         int i = base + threadIdx.x;
         uint32_t v = i < P ? c[i] : 0u;
         if (v > (uint32_t)kCapBig) over = 1;
+        if (v > vmax) vmax = v;
         sh[threadIdx.x] = v;
         __syncthreads();
         for (int d = 1; d < 1024; d <<= 1) {
@@ -165,6 +172,7 @@ __global__ void __launch_bounds__(1024) k_offsets(Geo g, const uint32_t *__restr
     }
     if (threadIdx.x == 0) o[P] = carry;
     if (over) ctl->overflow = 1;
+    if (vmax) atomicMax(&ctl->maxpart, vmax);
     // the LRU clock placeholder clock0 + 1 + position must stay a positive int
     if (threadIdx.x == 0 && (long long)st->clk + g.n + 2 >= 0x7fffffffLL) ctl->overflow = 1;
 }
@@ -203,15 +211,18 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
     Ctl *ctl, const int32_t *__restrict__ ids, const float *__restrict__ scores, const uint32_t *__restrict__ off,
     const uint32_t *__restrict__ items1, const uint32_t *__restrict__ evcnt /* [2][P1] */, const MoveEv *__restrict__ ev,
     EvRes *__restrict__ evres, uint8_t *__restrict__ miss, uint8_t *__restrict__ outm, MainBucket *__restrict__ stage_m,
-    uint32_t *__restrict__ stage_tot, uint8_t *__restrict__ hadev) {
+    uint32_t *__restrict__ stage_tot, uint32_t *__restrict__ prevcnt, uint8_t *__restrict__ ldirty /* [2][P2] */) {
     __shared__ unsigned long long key[CAP];
     __shared__ uint32_t px[CAP];
     __shared__ float pc[CAP];
     __shared__ uint8_t po[CAP];
+    __shared__ int heavy[kMaxHeavy];
+    __shared__ int n_heavy;
 
     if (ctl->final_round || st->fallback || ctl->overflow) return;
     const int p = blockIdx.x, tid = threadIdx.x;
     const int prev = (round & 1) ^ 1;
+    if (tid == 0) n_heavy = 0;
     const uint32_t o0 = off[p];
     const int np = (int)(off[p + 1] - o0);
     const uint32_t ne_raw = round > 1 ? evcnt[prev * g.P1 + p] : 0u;       // moves emitted by LRU round-1
@@ -220,12 +231,36 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
     const int total = np + ne;
     if (BIG ? (total <= kCapSmall) : (total > kCapSmall)) return;           // the other size class owns it
     if (total > CAP) { if (tid == 0) ctl->overflow = 1; return; }
-    if (round > 1 && ne == 0 && !hadev[p]) return;        // same inputs as last round: staged result stands
-    if (tid == 0) { hadev[p] = ne > 0; stage_tot[p] = (uint32_t)total; }
+    // Same moves as the last round this partition ran with => same result: its staged buckets, per-item
+    // outcomes and move outcomes stand.  Lists are compared as sets (arrival order is not deterministic).
+    const size_t evbase = (size_t)prev * g.P1 * kCapEv + (size_t)p * kCapEv;          // this round's moves
+    const size_t evold = (size_t)(prev ^ 1) * g.P1 * kCapEv + (size_t)p * kCapEv;     // the moves of the round before
+    if (round > 1) {
+        const int pne = (int)prevcnt[p];
+        int differ = ne != pne;
+        if (!differ) {
+            for (int t = tid; t < ne; t += kThreads) {
+                const MoveEv a = ev[evbase + t];
+                int found = 0;
+                for (int j = 0; j < ne; ++j) {
+                    const MoveEv b = ev[evold + j];
+                    found |= (a.time == b.time && a.x == b.x && __float_as_uint(a.cnt) == __float_as_uint(b.cnt) &&
+                              a.dic == b.dic && a.kind == b.kind);
+                }
+                differ |= !found;
+            }
+        }
+        differ = __syncthreads_or(differ);
+        if (tid == 0) prevcnt[p] = (uint32_t)ne;
+        if (!differ) return;
+    } else if (tid == 0) {
+        prevcnt[p] = 0;
+    }
+    if (tid == 0) stage_tot[p] = (uint32_t)total;
     if (total == 0) return;
     const int len = next_pow2(total);
     const int b0 = p * g.bpp1;
-    const size_t evbase = (size_t)p * kCapEv;
+    const int par = round & 1;
 
     for (int j = tid; j < len; j += kThreads) {
         unsigned long long k = ~0ull;
@@ -259,13 +294,19 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
 
     const float thr = st->thr;
     const uint32_t gflip = (uint32_t)st->flip;
-    MainBucket *stage = stage_m + o0 + evbase;
+    MainBucket *stage = stage_m + o0 + (size_t)p * kCapEv;
     MainCtx ctx;
     ctx.full = st->fifo_len > 0;
     int changed = 0;
+    // Phase A: one lane per bucket replays the bucket's items in batch order.  Buckets with many items (a
+    // heavy id) are left to phase B, where a whole wave works on one bucket.
     for (int s = tid; s < total; s += kThreads) {
         const uint32_t bl = (uint32_t)(key[s] >> 39);
         if (s != 0 && (uint32_t)(key[s - 1] >> 39) == bl) continue;
+        if (s + kHeavySeg <= total && (uint32_t)(key[s + kHeavySeg - 1] >> 39) == bl) {
+            int at = atomicAdd(&n_heavy, 1);
+            if (at < kMaxHeavy) { heavy[at] = s; continue; }
+        }
         MainR b;
         load_main(b, &mt[b0 + (int)bl]);
         sync_flip(b, gflip);
@@ -276,18 +317,88 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
                 ctx.pos = time >> 1; ctx.flags = 0;
                 int r = main_probe(b, px[e], pc[e], thr, ctx);
                 const bool m = r < 0;
-                if (m != (po[e] != 0)) changed = 1;
+                if (m != (po[e] != 0)) { changed = 1; ldirty[par * g.P2 + fast_hash(px[e], g.fm2) / g.bpp2] = 1; }
                 po[e] = (uint8_t)(ctx.flags | (m ? oMiss : 0) | (r > 0 ? oGot : 0));
             } else {
                 ctx.pushed = 0;
                 const int32_t dic = ev[evbase + (int)(k & 0x7fffu)].dic;
                 int ok = main_move(b, px[e], pc[e], dic, ctx);
                 EvRes r;
-                r.tag = call_tag | (unsigned)round; r.kind = ((k >> 15) & 1u) ? 1 : 2; r.ok = ok; r.pushed = ctx.pushed; r.pad = 0;
+                r.tag = call_tag; r.kind = ((k >> 15) & 1u) ? 1 : 2; r.ok = ok; r.pushed = ctx.pushed; r.pad = 0;
                 evres[time >> 1] = r;
             }
         }
         store_main(&stage[s], b, b0 + (int)bl);
+    }
+    __syncthreads();
+    // Phase B: heavy buckets, one per wave at a time.  All 64 lanes carry the same bucket copy.  A run of
+    // consecutive probes of one id that sits in the bucket only needs the ordered float sum of the scores on
+    // the serial path (one readlane + add per item); threshold crossing and the pop are then evaluated for 64
+    // items at once.  Anything else (misses, moves) takes the one-item step, executed uniformly.
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int nh = min(n_heavy, kMaxHeavy);
+        for (int h = wave; h < nh; h += kThreads / 64) {
+            const int s = heavy[h];
+            const uint32_t bl = (uint32_t)(key[s] >> 39);
+            MainR b;
+            load_main(b, &mt[b0 + (int)bl]);
+            sync_flip(b, gflip);
+            int e = s;
+            while (e < total && (uint32_t)(key[e] >> 39) == bl) {
+                const unsigned long long k0 = key[e];
+                const uint32_t time0 = (uint32_t)(k0 >> 16) & 0x7fffffu;
+                const uint32_t x0 = px[e];
+                const int hit = (time0 & 1u) ? -1 : find_slot(b, x0);
+                if (hit >= 0) {
+                    const int idx = e + lane;
+                    const bool in = idx < total;
+                    const unsigned long long kk = in ? key[idx] : ~0ull;
+                    const bool same = in && (uint32_t)(kk >> 39) == bl && !((uint32_t)(kk >> 16) & 1u) && px[idx] == x0;
+                    const unsigned long long m = __ballot(same);
+                    const int r = (~m) ? __builtin_ctzll(~m) : 64;            // length of the run starting at e (>= 1)
+                    const float c = in ? pc[idx] : 0.0f;
+                    float acc = sel4f(b.c0, b.c1, b.c2, b.c3, hit), mine = 0.0f;
+                    for (int j = 0; j < r; ++j) {
+                        acc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), j));
+                        mine = lane == j ? acc : mine;
+                    }
+                    const bool act = lane < r;
+                    const bool cross = act && mine >= thr && mine - c < thr;
+                    int32_t dic = sel4(b.d0, b.d1, b.d2, b.d3, hit);
+                    const unsigned long long pm = (!dic && ctx.full) ? __ballot(act && mine >= thr) : 0ull;
+                    const int kpop = pm ? __builtin_ctzll(pm) : -1;
+                    if (kpop >= 0) {
+                        const uint32_t tpop = (uint32_t)(key[e + kpop] >> 16) & 0x7fffffu;
+                        dic = (int32_t)(kSur | (tpop >> 1));
+                    }
+                    if (act) {
+                        if (po[idx] != 0) { changed = 1; ldirty[par * g.P2 + fast_hash(x0, g.fm2) / g.bpp2] = 1; }   // it missed last round
+                        po[idx] = (uint8_t)((cross ? oCross : 0) | (lane == kpop ? (oPop | oGot) : 0));
+                    }
+                    CAFE_SET4(b.c0, b.c1, b.c2, b.c3, hit, acc);
+                    CAFE_SET4(b.d0, b.d1, b.d2, b.d3, hit, dic);
+                    e += r;
+                } else if (!(time0 & 1u)) {
+                    if (lane == 0) {
+                        if (po[e] == 0) { changed = 1; ldirty[par * g.P2 + fast_hash(x0, g.fm2) / g.bpp2] = 1; }
+                        po[e] = oMiss;
+                    }
+                    e += 1;
+                } else {
+                    ctx.pushed = 0;
+                    const int32_t dic = ev[evbase + (int)(k0 & 0x7fffu)].dic;
+                    int ok = main_move(b, x0, pc[e], dic, ctx);
+                    if (lane == 0) {
+                        EvRes r;
+                        r.tag = call_tag; r.kind = ((k0 >> 15) & 1u) ? 1 : 2; r.ok = ok; r.pushed = ctx.pushed; r.pad = 0;
+                        evres[time0 >> 1] = r;
+                    }
+                    e += 1;
+                }
+            }
+            if (lane == 0) store_main(&stage[s], b, b0 + (int)bl);
+        }
     }
     __syncthreads();
     // parallel write-back of the per-item outcomes; entries that are not a bucket's first item are marked unused
@@ -326,12 +437,13 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
     Geo g, int round, const LruBucket *__restrict__ lt, const DevState *__restrict__ st, Ctl *ctl,
     const int32_t *__restrict__ ids, const float *__restrict__ scores, const uint32_t *__restrict__ off,
     const uint32_t *__restrict__ items2, const uint8_t *__restrict__ miss, uint32_t *evcnt, MoveEv *__restrict__ ev,
-    uint8_t *__restrict__ outl, LruBucket *__restrict__ stage_l, uint32_t *__restrict__ stage_tot) {
+    uint8_t *__restrict__ outl, LruBucket *__restrict__ stage_l, uint32_t *__restrict__ stage_tot,
+    uint8_t *__restrict__ ldirty /* [2][P2] */, MoveEv *__restrict__ myev /* [P2][kCapEvL] */, uint32_t *__restrict__ mycnt) {
     __shared__ unsigned long long key[CAP];
     __shared__ uint32_t px[CAP];
     __shared__ float pc[CAP];
     __shared__ uint8_t po[CAP];
-    __shared__ int n_miss;
+    __shared__ int n_miss, n_ev;
 
     if (ctl->final_round || st->fallback || ctl->overflow) return;
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -346,7 +458,22 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
     const int cnt = (int)(off[g.P1 + 1 + q + 1] - o0);
     if (BIG ? (cnt <= kCapSmall) : (cnt > kCapSmall)) return;
     if (cnt > CAP) { if (tid == 0) ctl->overflow = 1; return; }
-    if (tid == 0) n_miss = 0;
+    MoveEv *mine_ev = myev + (size_t)q * kCapEvL;
+    const bool dirty = round == 1 || ldirty[par * g.P2 + q];
+    if (tid == 0) ldirty[nxt * g.P2 + q] = 0;
+    if (!dirty) {
+        // none of this partition's items changed between hit and miss: same result, so only hand the moves it
+        // emitted last time to this round's lists
+        const int ne = (int)mycnt[q];
+        for (int j = tid; j < ne; j += kThreads) {
+            const MoveEv m = mine_ev[j];
+            const int p = m.pad[0];
+            uint32_t at = atomicAdd(&evcnt[par * g.P1 + p], 1u);
+            if (at < (uint32_t)kCapEv) ev[(size_t)par * g.P1 * kCapEv + (size_t)p * kCapEv + at] = m; else ctl->overflow = 1;
+        }
+        return;
+    }
+    if (tid == 0) { n_miss = 0; n_ev = 0; }
     __syncthreads();
     const int len0 = next_pow2(cnt);
     const int b0 = q * g.bpp2;
@@ -366,7 +493,7 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
     if (mine) atomicAdd(&n_miss, mine);
     __syncthreads();
     const int total = n_miss;
-    if (tid == 0) stage_tot[g.P1 + q] = (uint32_t)total;
+    if (tid == 0) { stage_tot[g.P1 + q] = (uint32_t)total; if (total == 0) mycnt[q] = 0; }
     if (total == 0) return;
     bitonic_sort(key, len0);
     for (int s = tid; s < total; s += kThreads) {
@@ -401,23 +528,22 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
                 lru_evict(b, -f - 1, mv);
                 got = lru_place(b, -f - 1, x, c, thr, ctx);
             }
-            po[e] = (uint8_t)(ctx.flags | (got ? oGot : 0));
+            po[e] = (uint8_t)(ctx.flags | (got ? oGot : 0) | (mv.kind ? oEv : 0));
             if (mv.kind) {
                 int p = fast_hash(mv.x, g.fm1) / g.bpp1;
+                MoveEv m;
+                m.time = 2u * pos + 1u; m.x = mv.x; m.cnt = mv.cnt; m.dic = mv.dic; m.kind = mv.kind;
+                m.pad[0] = p; m.pad[1] = m.pad[2] = 0;
                 uint32_t at = atomicAdd(&evcnt[par * g.P1 + p], 1u);
-                if (at < (uint32_t)kCapEv) {
-                    MoveEv m;
-                    m.time = 2u * pos + 1u; m.x = mv.x; m.cnt = mv.cnt; m.dic = mv.dic; m.kind = mv.kind;
-                    m.pad[0] = m.pad[1] = m.pad[2] = 0;
-                    ev[(size_t)p * kCapEv + at] = m;
-                } else {
-                    over = 1;
-                }
+                if (at < (uint32_t)kCapEv) ev[(size_t)par * g.P1 * kCapEv + (size_t)p * kCapEv + at] = m; else over = 1;
+                int mi = atomicAdd(&n_ev, 1);
+                if (mi < kCapEvL) mine_ev[mi] = m; else over = 1;
             }
         }
         store_lru(&stage[s], b, b0 + (int)bl);
     }
     __syncthreads();
+    if (tid == 0) mycnt[q] = (uint32_t)min(n_ev, kCapEvL);
     for (int s = tid; s < total; s += kThreads) {
         outl[(uint32_t)key[s]] = po[s];
         if (s != 0 && (uint32_t)(key[s - 1] >> 32) == (uint32_t)(key[s] >> 32))
@@ -450,7 +576,7 @@ __global__ void __launch_bounds__(kScanBlock) k_finish_flags(
         int32_t pv = 0;
         if (m) {
             const EvRes r = evres[i];
-            if (r.tag == (call_tag | ctl->final_round)) {
+            if ((o & oEv) && r.tag == call_tag) {
                 if (r.kind == 1 && !r.ok) got = 0;           // sketch.cpp:180-182
                 if (!r.ok && r.pushed != 0) { push = 1; pv = r.pushed; }
             }
@@ -476,53 +602,52 @@ __global__ void __launch_bounds__(kScanBlock) k_finish_flags(
     }
 }
 
-// one workgroup: exclusive scan of the per-block sums (in place), totals, the free-list check, decision
-__global__ void __launch_bounds__(256) k_finish_decide(Geo g, int nblocks, DevState *st, Ctl *ctl, uint32_t *blocksum) {
-    __shared__ unsigned long long wtot[4][4];
-    __shared__ unsigned long long carry[4];
-    const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;      // one wave per counter
-    unsigned long long run = 0;                                   // identical in every lane of the wave
-    for (int base = 0; base < nblocks; base += 64) {
-        const int b = base + lane;
-        uint32_t v = b < nblocks ? blocksum[b * 4 + c] : 0u;
-        uint32_t incl = v;
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
-        if (b < nblocks) blocksum[b * 4 + c] = (uint32_t)run + incl - v;
-        run += __shfl(incl, 63, 64);
-    }
-    if (lane == 0) carry[c] = run;
-    __syncthreads();
-    (void)wtot;
-    if (threadIdx.x == 0) {
-        bool ok = !(st->fallback || ctl->overflow) && ctl->final_round != 0;
-        if (ok) {
-            if (st->fifo_len > 0) ok = carry[0] <= (unsigned long long)st->fifo_len;      // never ran dry
-            else ok = carry[1] == 0;                                                       // never refilled
-        }
-        ctl->tot_pop = (uint32_t)carry[0]; ctl->tot_push = (uint32_t)carry[1]; ctl->tot_clk = (uint32_t)carry[2];
-        ctl->tot_cross = carry[3];
-        st->rounds = (int32_t)ctl->final_round;
-        if (!ok) st->fallback = 1;
-    }
-}
-
-// per-item exclusive ranks in batch order
-__global__ void __launch_bounds__(kScanBlock) k_finish_ranks(Geo g, const DevState *st, const uint8_t *__restrict__ flags,
+// per-item exclusive ranks in batch order.  Every workgroup sums the block totals in front of it; workgroup 0 also
+// forms the batch totals, checks the free-list assumption and decides whether the result may be committed.
+__global__ void __launch_bounds__(kScanBlock) k_finish_ranks(Geo g, int nblocks, DevState *st, Ctl *ctl,
+                                                             const uint8_t *__restrict__ flags,
                                                              const uint32_t *__restrict__ blocksum, uint32_t *__restrict__ poprank,
                                                              uint32_t *__restrict__ pushrank, uint32_t *__restrict__ clkrank) {
     __shared__ uint32_t wsum[3][kScanBlock / 64];
-    if (st->fallback) return;
+    __shared__ unsigned long long red[4][kScanBlock / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // sums of the block totals: [0, blockIdx) for the offsets; workgroup 0 takes all blocks for the totals
+    const int upto = blockIdx.x == 0 ? nblocks : (int)blockIdx.x;
+    unsigned long long part[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < upto; b += blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4 *>(blocksum)[b];
+        part[0] += v.x; part[1] += v.y; part[2] += v.z; part[3] += v.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        unsigned long long v = part[c];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[c][w] = v;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint8_t f = i < g.n ? flags[i] : 0;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1;
     unsigned long long m0 = __ballot(f & 1), m1 = __ballot(f & 2), m2 = __ballot(f & 4);
     if (lane == 0) { wsum[0][w] = __popcll(m0); wsum[1][w] = __popcll(m1); wsum[2][w] = __popcll(m2); }
     __syncthreads();
-    uint32_t o0 = blocksum[blockIdx.x * 4 + 0], o1 = blocksum[blockIdx.x * 4 + 1], o2 = blocksum[blockIdx.x * 4 + 2];
+    unsigned long long tot[4] = {0, 0, 0, 0};
+    for (int k = 0; k < kScanBlock / 64; ++k) { tot[0] += red[0][k]; tot[1] += red[1][k]; tot[2] += red[2][k]; tot[3] += red[3][k]; }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            bool ok = !(st->fallback || ctl->overflow) && ctl->final_round != 0;
+            if (ok) {
+                if (st->fifo_len > 0) ok = tot[0] <= (unsigned long long)st->fifo_len;      // never ran dry
+                else ok = tot[1] == 0;                                                       // never refilled
+            }
+            ctl->totals[0] = (uint32_t)tot[0]; ctl->totals[1] = (uint32_t)tot[1]; ctl->totals[2] = (uint32_t)tot[2];
+            ctl->totals[3] = (uint32_t)tot[3]; ctl->totals[4] = ctl->final_round;
+            st->rounds = (int32_t)ctl->final_round;
+            st->maxpart = (int32_t)ctl->maxpart;
+            if (!ok) st->fallback = 1;
+        }
+        tot[0] = tot[1] = tot[2] = 0;                 // block 0 starts at rank 0
+    }
+    uint32_t o0 = (uint32_t)tot[0], o1 = (uint32_t)tot[1], o2 = (uint32_t)tot[2];
     for (int k = 0; k < w; ++k) { o0 += wsum[0][k]; o1 += wsum[1][k]; o2 += wsum[2][k]; }
     if (i < g.n) {
         poprank[i] = o0 + (uint32_t)__popcll(m0 & below);
@@ -585,7 +710,7 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, MainBucket *mt, LruBucket
             }
         }
     }
-    if (ctl->tot_push == 0) return;
+    if (ctl->totals[1] == 0) return;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += (long)gridDim.x * blockDim.x) {
         if (flags[i] & 2) {
             // pushes land behind everything the list held; pops only ever take what it held at the start
@@ -593,18 +718,6 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, MainBucket *mt, LruBucket
             fifo[(unsigned long long)((unsigned long long)head + len0 + pushrank[i]) % cap] = (uint32_t)d;
         }
     }
-}
-
-__global__ void k_commit_scalars(DevState *st, const Ctl *ctl, uint32_t cap) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (st->fallback) { st->pad[0] += 1; return; }      // cumulative: batches handed to the in-order kernel
-    st->pad[1] += (int32_t)ctl->final_round;            // cumulative rounds
-    if ((int32_t)ctl->final_round > st->pad[2]) st->pad[2] = (int32_t)ctl->final_round;
-    st->fifo_head = (uint32_t)(((unsigned long long)st->fifo_head + ctl->tot_pop) % cap);
-    st->fifo_len = st->fifo_len + ctl->tot_push - ctl->tot_pop;
-    st->num += (int32_t)ctl->tot_pop;
-    st->real_n += (int32_t)ctl->tot_cross;
-    st->clk += (int32_t)ctl->tot_clk;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -627,11 +740,12 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     g.fm2 = make_fastmod(s->n2);
     const size_t N = (size_t)n, PP = (size_t)g.P1 + g.P2;
     const int nblocks = (n + kScanBlock - 1) / kScanBlock;
-    if (w.ctl.reserve(sizeof(Ctl)) || w.cnt.reserve(4 * PP + 4) || w.off.reserve(4 * PP + 16) || w.rank.reserve(8 * N) ||
-        w.items.reserve(8 * N) || w.evcnt.reserve(8 * (size_t)g.P1) || w.ev.reserve(sizeof(MoveEv) * (size_t)g.P1 * kCapEv) ||
+    if (w.zr.reserve(4 * (kCtlWords + PP + 2 * (size_t)g.P1) + 16) || w.off.reserve(4 * PP + 16) || w.rank.reserve(8 * N) ||
+        w.items.reserve(8 * N) || w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * kCapEv) ||
         w.evres.reserve(sizeof(EvRes) * N) || w.miss.reserve(N) || w.outm.reserve(N) || w.outl.reserve(N) ||
         w.stage_m.reserve(sizeof(MainBucket) * (N + (size_t)g.P1 * kCapEv)) || w.stage_l.reserve(sizeof(LruBucket) * N) ||
-        w.stage_tot.reserve(4 * PP + 4) || w.hadev.reserve((size_t)g.P1 + 4) || w.flags.reserve(5 * N + 64) ||
+        w.stage_tot.reserve(4 * PP + 4) || w.prevcnt.reserve(4 * (size_t)g.P1 + 4) || w.ldirty.reserve(2 * (size_t)g.P2 + 4) ||
+        w.myev.reserve(sizeof(MoveEv) * (size_t)g.P2 * kCapEvL) || w.mycnt.reserve(4 * (size_t)g.P2 + 4) || w.flags.reserve(5 * N + 64) ||
         w.blocksum.reserve(16 * (size_t)nblocks + 16) || w.ranks.reserve(12 * N))
         return 1;
     if (w.evres.p != w.evres_seen) {      // tags of a fresh allocation must not match by accident
@@ -641,43 +755,74 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     return 0;
 }
 
+int par_prepare(cafe_sketch *s, int n, uint32_t **zero, int *zero_words) {
+    *zero = nullptr; *zero_words = 0;
+    if (n > (1 << 21)) return 0;          // such a batch goes to the in-order kernel (23-bit time field of the sort keys)
+    Geo g;
+    if (ensure_ws(s, n, g)) return 1;
+    *zero = s->par->zr.as<uint32_t>();
+    *zero_words = (int)(kCtlWords + (size_t)g.P1 + g.P2 + 2 * (size_t)g.P1);
+    return 0;
+}
+
+// How many rounds to enqueue and whether to enqueue the big-partition variants are guesses from what recent calls
+// needed (a pinned copy of the device state trails every insert).  A wrong guess is never a wrong result: a batch
+// that is not settled, or meets a partition without an owner kernel, is handed to the in-order kernel untouched.
+static void launch_plan(cafe_sketch *s, int n, int &rounds, bool &big) {
+    const int max_rounds = std::min(std::max(s->opt_max_rounds, 1), kMaxRounds) + 1;
+    const DevState *fb = reinterpret_cast<const DevState *>(s->h_pinned);
+    rounds = max_rounds;
+    big = true;
+    if (s->last_seen_batch != n) {         // other batch size: forget what was learnt
+        for (int &h : s->hint_rounds) h = 0;
+        s->last_seen_batch = n;
+        return;
+    }
+    if (fb->fallback || fb->rounds <= 0) { for (int &h : s->hint_rounds) h = 0; return; }
+    s->hint_rounds[s->hint_pos++ & 7] = fb->rounds;
+    int known = 0, most = 0;
+    for (int h : s->hint_rounds) { known += h > 0; most = std::max(most, h); }
+    if (known >= 4) rounds = std::min(max_rounds, most + 2);
+    if (known >= 4 && fb->maxpart > 0 && (long)fb->maxpart * 3 / 2 + kCapEv <= kCapSmall) big = false;
+}
+
 int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st) {
     Geo g;
     if (n > (1 << 21)) {     // the 23-bit time field of the owners' sort key
         s->counters[2]++;
         return launch_serial_insert(s, d_ids, d_scores, n, d_ins, 0, st);
     }
-    if (ensure_ws(s, n, g)) return 1;
+    if (ensure_ws(s, n, g)) return 1;      // sized by par_prepare already; the prologue kernel zeroed w.zr
     ParWorkspace &w = *s->par;
     w.call_seq++;
-    const unsigned long long tag = w.call_seq << 8;
-    Ctl *ctl = w.ctl.as<Ctl>();
-    uint32_t *cnt = w.cnt.as<uint32_t>(), *off = w.off.as<uint32_t>();
+    const unsigned long long tag = w.call_seq;
+    Ctl *ctl = w.zr.as<Ctl>();
+    uint32_t *cnt = w.zr.as<uint32_t>() + kCtlWords, *evcnt = cnt + g.P1 + g.P2;
+    uint32_t *off = w.off.as<uint32_t>();
     uint32_t *rank1 = w.rank.as<uint32_t>(), *rank2 = rank1 + n;
     uint32_t *items1 = w.items.as<uint32_t>(), *items2 = items1 + n;
-    uint32_t *evcnt = w.evcnt.as<uint32_t>(), *stage_tot = w.stage_tot.as<uint32_t>();
-    CAFE_HIP_CHECK(hipMemsetAsync(ctl, 0, sizeof(Ctl), st));
-    CAFE_HIP_CHECK(hipMemsetAsync(cnt, 0, 4 * ((size_t)g.P1 + g.P2), st));
-    CAFE_HIP_CHECK(hipMemsetAsync(evcnt, 0, 8 * (size_t)g.P1, st));
+    uint32_t *stage_tot = w.stage_tot.as<uint32_t>();
     const int gb = (n + 255) / 256;
     hipLaunchKernelGGL(k_assign, dim3((n + kAssignChunk - 1) / kAssignChunk), dim3(1024), 4 * (size_t)(g.P1 + g.P2), st, g,
                        d_ids, cnt, rank1, rank2);
     hipLaunchKernelGGL(k_offsets, dim3(2), dim3(1024), 0, st, g, cnt, off, ctl, s->d_state);
     hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, g, d_ids, off, rank1, rank2, items1, items2);
-    const int rounds = std::min(std::max(s->opt_max_rounds, 1), kMaxRounds);
+    int rounds;
+    bool big;
+    launch_plan(s, n, rounds, big);
 #define CAFE_MAIN(CAPV, BIGV)                                                                                              \
     hipLaunchKernelGGL((k_main_round<CAPV, BIGV>), dim3(g.P1), dim3(kThreads), 0, st, g, r, tag, s->d_main, s->d_state, ctl, \
                        d_ids, d_scores, off, items1, evcnt, w.ev.as<MoveEv>(), w.evres.as<EvRes>(), w.miss.as<uint8_t>(),    \
-                       w.outm.as<uint8_t>(), w.stage_m.as<MainBucket>(), stage_tot, w.hadev.as<uint8_t>())
+                       w.outm.as<uint8_t>(), w.stage_m.as<MainBucket>(), stage_tot, w.prevcnt.as<uint32_t>(), w.ldirty.as<uint8_t>())
 #define CAFE_LRU(CAPV, BIGV)                                                                                               \
     hipLaunchKernelGGL((k_lru_round<CAPV, BIGV>), dim3(g.P2), dim3(kThreads), 0, st, g, r, s->d_lru, s->d_state, ctl, d_ids, \
                        d_scores, off, items2, w.miss.as<uint8_t>(), evcnt, w.ev.as<MoveEv>(), w.outl.as<uint8_t>(),          \
-                       w.stage_l.as<LruBucket>(), stage_tot)
-    for (int r = 1; r <= rounds + 1; ++r) {
+                       w.stage_l.as<LruBucket>(), stage_tot, w.ldirty.as<uint8_t>(), w.myev.as<MoveEv>(), w.mycnt.as<uint32_t>())
+    for (int r = 1; r <= rounds; ++r) {
         CAFE_MAIN(kCapSmall, false);
-        CAFE_MAIN(kCapBig, true);
+        if (big) CAFE_MAIN(kCapBig, true);
         CAFE_LRU(kCapSmall, false);
-        CAFE_LRU(kCapBig, true);
+        if (big) CAFE_LRU(kCapBig, true);
     }
 #undef CAFE_MAIN
 #undef CAFE_LRU
@@ -688,17 +833,16 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     hipLaunchKernelGGL(k_finish_flags, dim3(nb), dim3(kScanBlock), 0, st, g, tag, s->d_state, ctl, w.miss.as<uint8_t>(),
                        w.outm.as<uint8_t>(), w.outl.as<uint8_t>(), w.evres.as<EvRes>(), d_ins, flags, pushval,
                        w.blocksum.as<uint32_t>());
-    hipLaunchKernelGGL(k_finish_decide, dim3(1), dim3(256), 0, st, g, nb, s->d_state, ctl, w.blocksum.as<uint32_t>());
-    hipLaunchKernelGGL(k_finish_ranks, dim3(nb), dim3(kScanBlock), 0, st, g, s->d_state, flags, w.blocksum.as<uint32_t>(),
-                       poprank, pushrank, clkrank);
+    hipLaunchKernelGGL(k_finish_ranks, dim3(nb), dim3(kScanBlock), 0, st, g, nb, s->d_state, ctl, flags,
+                       w.blocksum.as<uint32_t>(), poprank, pushrank, clkrank);
     const int cb = std::min(g.P1 + g.P2, 2048);
     hipLaunchKernelGGL(k_commit, dim3(cb), dim3(256), 0, st, g, s->d_main, s->d_lru, s->d_fifo, s->fifo_cap, s->d_state, ctl,
                        off, stage_tot, w.stage_m.as<MainBucket>(), w.stage_l.as<LruBucket>(), flags, pushval, poprank,
                        pushrank, clkrank);
-    hipLaunchKernelGGL(k_commit_scalars, dim3(1), dim3(64), 0, st, s->d_state, ctl, s->fifo_cap);
     CAFE_HIP_CHECK(hipGetLastError());
-    // batches the owners could not settle run in order, from the untouched tables
-    if (launch_serial_insert(s, d_ids, d_scores, n, d_ins, 1, st)) return 1;
+    // closing kernel: applies the batch totals to the device scalars, or, for a batch the owners could not settle,
+    // runs it in order from the untouched tables
+    if (launch_serial_insert(s, d_ids, d_scores, n, d_ins, 1, st, ctl->totals)) return 1;
     s->counters[1]++;
     return 0;
 }
@@ -706,8 +850,8 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
 void par_free(cafe_sketch *s) {
     if (!s->par) return;
     ParWorkspace &w = *s->par;
-    DevBuf *all[] = {&w.ctl, &w.cnt, &w.off, &w.rank, &w.items, &w.evcnt, &w.ev, &w.evres, &w.miss, &w.outm, &w.outl,
-                     &w.stage_m, &w.stage_l, &w.stage_tot, &w.hadev, &w.flags, &w.blocksum, &w.ranks};
+    DevBuf *all[] = {&w.zr, &w.off, &w.rank, &w.items, &w.ev, &w.evres, &w.miss, &w.outm, &w.outl,
+                     &w.stage_m, &w.stage_l, &w.stage_tot, &w.prevcnt, &w.ldirty, &w.myev, &w.mycnt, &w.flags, &w.blocksum, &w.ranks};
     for (DevBuf *b : all) b->release();
     delete s->par;
     s->par = nullptr;

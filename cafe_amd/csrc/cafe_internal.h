@@ -55,7 +55,10 @@ struct cafe_sketch {
     // workspaces
     cafe::DevBuf ws_reset_keys, ws_reset_keys2, ws_reset_tmp, ws_reset_flags, ws_misc;
     cafe::ParWorkspace *par = nullptr;
-    int32_t *h_pinned = nullptr;    // small pinned readback area
+    int32_t *h_pinned = nullptr;    // pinned copy of DevState, refreshed behind every insert (lagging feedback)
+    int hint_rounds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // final round counts of recent calls (0 = unknown)
+    int hint_pos = 0;
+    long long last_seen_batch = -1;
     hipEvent_t ev_real_n = nullptr; // recorded after the async readback of real_n that ends every insert
     bool real_n_pending = false;
 };
@@ -74,8 +77,10 @@ struct cafe_tables {
 namespace cafe {
 // cafe_insert_par.hip
 int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st);
+// region the per-call prologue kernel has to zero for a parallel insert of n ids (nullptr: none)
+int par_prepare(cafe_sketch *s, int n, uint32_t **zero, int *zero_words);
 void par_free(cafe_sketch *s);
 // cafe_sketch.hip
 int launch_serial_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
-                         int only_if_fallback, hipStream_t st);
+                         int only_if_fallback, hipStream_t st, const uint32_t *par_totals = nullptr);
 }  // namespace cafe

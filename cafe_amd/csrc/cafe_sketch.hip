@@ -103,12 +103,12 @@ __global__ void k_count(const MainBucket *__restrict__ mt, int n1, const int32_t
 // per-call prologue (sketch.cpp:282-289): the flip decision is made on the host (it depends on the
 // call count only); the threshold lives on the device because reset() rewrites it there.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_prologue(DevState *st, int flip_now, int gflip) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+__global__ void __launch_bounds__(1024) k_prologue(DevState *st, int flip_now, int gflip, uint32_t *zero, int zero_words) {
+    for (int i = threadIdx.x; i < zero_words; i += blockDim.x) zero[i] = 0;      // control words of the parallel insert
+    if (threadIdx.x == 0) {
         if (flip_now) st->thr = (float)((double)st->thr / kDecayV);
         st->flip = gflip;
         st->fallback = 0;
-        st->need_reset = 0;
         st->rounds = 0;
         st->converged = 0;
     }
@@ -144,9 +144,20 @@ struct SerialCtx {
 __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket *lt, uint32_t *fifo, uint32_t cap,
                                                       DevState *st, int n1, int n2, const int32_t *__restrict__ ids,
                                                       const float *__restrict__ scores, int n, int32_t *__restrict__ ins,
-                                                      int only_if_fallback) {
+                                                      int only_if_fallback, const uint32_t *par_totals) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (only_if_fallback && !st->fallback) return;
+    if (only_if_fallback && !st->fallback) {
+        // the parallel insert settled: apply its batch totals (pops, pushes, clock ticks, crossings, rounds)
+        st->fifo_head = (uint32_t)(((unsigned long long)st->fifo_head + par_totals[0]) % cap);
+        st->fifo_len = st->fifo_len + par_totals[1] - par_totals[0];
+        st->num += (int32_t)par_totals[0];
+        st->clk += (int32_t)par_totals[2];
+        st->real_n += (int32_t)par_totals[3];
+        st->pad[1] += (int32_t)par_totals[4];
+        if ((int32_t)par_totals[4] > st->pad[2]) st->pad[2] = (int32_t)par_totals[4];
+        return;
+    }
+    if (only_if_fallback) st->pad[0] += 1;          // cumulative: batches handed to the in-order kernel
     SerialCtx ctx;
     ctx.fifo = fifo; ctx.cap = cap; ctx.head = st->fifo_head; ctx.len = st->fifo_len;
     ctx.num = st->num; ctx.real_n = st->real_n; ctx.clk = st->clk;
@@ -191,9 +202,9 @@ __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket 
 }
 
 int cafe::launch_serial_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
-                               int only_if_fallback, hipStream_t st) {
+                               int only_if_fallback, hipStream_t st, const uint32_t *par_totals) {
     hipLaunchKernelGGL(k_insert_serial, dim3(1), dim3(64), 0, st, s->d_main, s->d_lru, s->d_fifo, s->fifo_cap,
-                       s->d_state, s->n1, s->n2, d_ids, d_scores, n, d_ins, only_if_fallback);
+                       s->d_state, s->n1, s->n2, d_ids, d_scores, n, d_ins, only_if_fallback, par_totals);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -366,6 +377,7 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     CAFE_HIP_CHECK(hipMalloc(&s->d_fifo, sizeof(uint32_t) * (size_t)s->fifo_cap));
     CAFE_HIP_CHECK(hipMalloc(&s->d_state, sizeof(DevState)));
     CAFE_HIP_CHECK(hipHostMalloc((void **)&s->h_pinned, 256, hipHostMallocDefault));
+    memset(s->h_pinned, 0, 256);
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_real_n, hipEventDisableTiming));
     if (s->ws_misc.reserve(4096)) return 1;
     CAFE_HIP_CHECK(hipMemset(s->d_main, 0, sizeof(MainBucket) * (size_t)s->n1));
@@ -619,14 +631,18 @@ extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const flo
     s->decay *= s->alpha;
     int flip_now = 0;
     if (s->decay > kDecayV) { s->decay /= kDecayV; s->flip ^= 1; flip_now = 1; }
-    hipLaunchKernelGGL(k_prologue, dim3(1), dim3(64), 0, st, s->d_state, flip_now, s->flip);
+    const bool parallel = !s->opt_serial && n > 0;
+    uint32_t *zero = nullptr;
+    int zero_words = 0;
+    if (parallel && par_prepare(s, n, &zero, &zero_words)) return 1;
+    hipLaunchKernelGGL(k_prologue, dim3(1), dim3(1024), 0, st, s->d_state, flip_now, s->flip, zero, zero_words);
     // sketch.cpp:291.  real_n after the previous insert was copied to pinned memory behind that insert; waiting
     // for that copy (normally long done: later kernels of the step were queued behind it) gives the exact value.
     if (s->adjust && (double)s->real_n_ub > s->lim * 1.2) {
         if (s->real_n_pending) {
             CAFE_HIP_CHECK(hipEventSynchronize(s->ev_real_n));
             s->real_n_pending = false;
-            s->real_n_ub = s->h_pinned[0];
+            s->real_n_ub = reinterpret_cast<const DevState *>(s->h_pinned)->real_n;
         }
         if ((double)s->real_n_ub > s->lim * 1.2) {
             if (run_reset(s, st)) return 1;
@@ -643,8 +659,8 @@ extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const flo
         rc = par_insert(s, d_ids, d_scores, n, d_ins, st);
     }
     s->real_n_ub += n;        // upper bound until the readback below is consumed
-    if (rc == 0 && s->adjust) {
-        CAFE_HIP_CHECK(hipMemcpyAsync(s->h_pinned, &s->d_state->real_n, 4, hipMemcpyDeviceToHost, st));
+    if (rc == 0) {
+        CAFE_HIP_CHECK(hipMemcpyAsync(s->h_pinned, s->d_state, sizeof(DevState), hipMemcpyDeviceToHost, st));
         CAFE_HIP_CHECK(hipEventRecord(s->ev_real_n, st));
         s->real_n_pending = true;
     }
