@@ -110,6 +110,11 @@ class CafeEmbeddingCollection:
         scores = self._get("scores", (n,), torch.float32)
         ins = self._get("ins", (n,), torch.int32)
         st = _stream()
+        if not per_field_calls:
+            _lib.check(self.L.cafe_backward_update_dev(self.sketch.h, self.tables, _ptr(self._ids), _ptr(gids), _ptr(que),
+                                                       _ptr(grad_out), B, ctypes.c_float(lr), _ptr(scores), _ptr(ins), st),
+                       "cafe_backward_update_dev")
+            return scores, ins
         _lib.check(self.L.cafe_scores_dev(self.tables, _ptr(grad_out), B, _ptr(scores), st), "cafe_scores_dev")
         if per_field_calls:
             for f in range(self.F):

@@ -3,8 +3,6 @@
 // the sparse backward + SGD update.  Behaviour follows tricks/sk_embedding_bag.py (cited per kernel).
 #include <hip/hip_runtime.h>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -263,79 +261,193 @@ extern "C" int cafe_migrate_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const in
 // (dlrm_s_pytorch.py:1658).  Here: unified row keys -> sort -> segment sums -> one read-modify-write per
 // touched row.  Segments that cross a chunk border finish with float atomics.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_row_keys(const int32_t *__restrict__ fields, const int32_t *__restrict__ que,
-                           const int32_t *__restrict__ hash_size, const int64_t *__restrict__ cold_base, int hotn,
-                           int batch, int total, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+constexpr int kBwdChunk = 8192;     // items per workgroup of the partitioning pass
+constexpr int kBwdCap = 1024;       // items a workgroup sorts in LDS (larger partitions are cut into tiles)
+constexpr int kBwdMaxBins = 8192;
+constexpr int kBwdTarget = 256;     // average items per partition
+constexpr int kBwdCH = 8;           // items a lane group takes at a time
+
+__device__ inline uint32_t row_key(const int32_t *__restrict__ fields, const int32_t *__restrict__ que,
+                                   const int32_t *__restrict__ hash_size, const int64_t *__restrict__ cold_base, int hotn,
+                                   int batch, int i) {
     const int32_t q = que[i];
-    uint32_t k;
-    if (q < 0) {
-        k = (uint32_t)(-q) % (uint32_t)hotn;
-    } else {
-        const int f = fields ? fields[i] : i / batch;
-        k = (uint32_t)hotn + (uint32_t)cold_base[f] + (uint32_t)q % (uint32_t)hash_size[f];
-    }
-    keys[i] = k;
-    vals[i] = (uint32_t)i;
+    if (q < 0) return (uint32_t)(-q) % (uint32_t)hotn;
+    const int f = fields ? fields[i] : i / batch;
+    return (uint32_t)hotn + (uint32_t)cold_base[f] + (uint32_t)q % (uint32_t)hash_size[f];
 }
 
-template <int LPG, int CHUNK>
-__global__ void __launch_bounds__(256) k_segment_sgd(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                     const int32_t *__restrict__ fields,
-                                                     const float *__restrict__ grad, float *__restrict__ w_hot,
-                                                     float *const *__restrict__ w_cold, const int64_t *__restrict__ cold_base,
-                                                     int hotn, int batch, int total, int dim, float lr) {
-    static_assert(LPG <= 64, "group within a wave");
-    const int lig = threadIdx.x % LPG;
-    const int chunk = (blockIdx.x * blockDim.x + threadIdx.x) / LPG;
-    const int begin = chunk * CHUNK;
-    if (begin >= total) return;
-    const int end = min(begin + CHUNK, total);
+// Partition the lookups by table row (key % P): every row's gradients meet in one workgroup, so closed segments are
+// updated with a plain read-modify-write and nothing needs a device-wide sort.
+__global__ void __launch_bounds__(1024) k_bwd_assign(int P, const int32_t *__restrict__ fields, const int32_t *__restrict__ que,
+                                                     const int32_t *__restrict__ hash_size, const int64_t *__restrict__ cold_base,
+                                                     int hotn, int batch, int total, uint32_t *__restrict__ cnt,
+                                                     uint32_t *__restrict__ rank, uint32_t *__restrict__ keys) {
+    extern __shared__ uint32_t hist[];
+    for (int b = threadIdx.x; b < P; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const int begin = blockIdx.x * kBwdChunk, end = min(begin + kBwdChunk, total);
+    for (int i = begin + threadIdx.x; i < end; i += blockDim.x) {
+        const uint32_t k = row_key(fields, que, hash_size, cold_base, hotn, batch, i);
+        keys[i] = k;
+        rank[i] = atomicAdd(&hist[k % (uint32_t)P], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < P; b += blockDim.x) {
+        const uint32_t c = hist[b];
+        if (c) hist[b] = atomicAdd(&cnt[b], c);
+    }
+    __syncthreads();
+    for (int i = begin + threadIdx.x; i < end; i += blockDim.x) rank[i] += hist[keys[i] % (uint32_t)P];
+}
+
+// offsets of the partitions, and the list of (partition, tile) work items: one workgroup per <= kBwdCap pairs
+__global__ void __launch_bounds__(1024) k_bwd_offsets(int P, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off,
+                                                      uint32_t *__restrict__ tiles /* [0] = count, then (p << 8 | t)... */) {
+    __shared__ uint32_t sh[1024], sh2[1024];
+    __shared__ uint32_t carry, carry2;
+    if (threadIdx.x == 0) { carry = 0; carry2 = 0; }
+    __syncthreads();
+    for (int base = 0; base < P; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < P ? cnt[i] : 0u;
+        const uint32_t nt = min((v + kBwdCap - 1) / kBwdCap, 256u);   // tile 255 walks whatever is left
+        sh[threadIdx.x] = v; sh2[threadIdx.x] = nt;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const uint32_t add = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0u;
+            const uint32_t add2 = (int)threadIdx.x >= d ? sh2[threadIdx.x - d] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += add; sh2[threadIdx.x] += add2;
+            __syncthreads();
+        }
+        if (i < P) {
+            off[i] = carry + sh[threadIdx.x] - v;
+            const uint32_t t0 = carry2 + sh2[threadIdx.x] - nt;
+            for (uint32_t t = 0; t < nt; ++t) tiles[1 + t0 + t] = ((uint32_t)i << 8) | t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry += sh[1023]; carry2 += sh2[1023]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { off[P] = carry; tiles[0] = carry2; }
+}
+
+__global__ void k_bwd_scatter(int P, int total, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ rank,
+                              const uint32_t *__restrict__ off, uint32_t *__restrict__ cnt, unsigned long long *__restrict__ items) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P) cnt[i] = 0;                       // ready for the next call (k_bwd_offsets has consumed it)
+    if (i >= total) return;
+    const uint32_t k = keys[i];
+    items[off[k % (uint32_t)P] + rank[i]] = ((unsigned long long)k << 32) | (uint32_t)i;
+}
+
+__device__ inline float *row_ptr(uint32_t key, uint32_t item, const int32_t *__restrict__ fields, float *__restrict__ w_hot,
+                                 float *const *__restrict__ w_cold, const int64_t *__restrict__ cold_base, int hotn, int batch,
+                                 int dim) {
+    if (key < (uint32_t)hotn) return w_hot + (size_t)key * dim;
+    const int f = fields ? fields[item] : (int)(item / (uint32_t)batch);
+    return w_cold[f] + (size_t)((int64_t)(key - (uint32_t)hotn) - cold_base[f]) * dim;
+}
+
+// One workgroup per partition: sort the partition's (row, lookup) pairs in LDS, then lane groups of LPG lanes walk
+// chunks of kBwdCH consecutive pairs: the chunk's gradient rows are fetched together, summed per row in lookup order,
+// and each row gets W -= lr * sum.  A row whose pairs all lie inside one chunk is updated with a plain
+// read-modify-write; a row spread over several chunks finishes with float atomics.
+template <int LPG, int VPL>
+__global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tiles,
+                                                      const unsigned long long *__restrict__ items,
+                                                      const int32_t *__restrict__ fields, const float *__restrict__ grad,
+                                                      float *__restrict__ w_hot, float *const *__restrict__ w_cold,
+                                                      const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr) {
+    __shared__ unsigned long long key[kBwdCap];
+    const int tid = threadIdx.x;
+    if (blockIdx.x >= tiles[0]) return;
+    // the tile index is kept in 8 bits; a partition with more tiles lets its last workgroup walk the rest
+    const uint32_t tl = tiles[1 + blockIdx.x];
+    const int p = (int)(tl >> 8), tile = (int)(tl & 255u);
+    const uint32_t o0 = off[p];
+    const int cnt = (int)(off[p + 1] - o0);
+    const int lig = tid % LPG, grp = tid / LPG;
+    constexpr int G = 256 / LPG;
     const int dim4 = dim >> 2;
-    constexpr int MAXV = 4;               // float4 per lane: dim <= LPG*4*MAXV (host checks)
-    float4 acc[MAXV];
-    int s = begin;
-    while (s < end) {
-        const uint32_t key = keys[s];
-#pragma unroll
-        for (int v = 0; v < MAXV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        int e = s;
-        while (e < end && keys[e] == key) {
-            const float4 *g = reinterpret_cast<const float4 *>(grad + (size_t)vals[e] * dim);
-#pragma unroll
-            for (int v = 0; v < MAXV; ++v) {
-                int c = lig + v * LPG;
-                if (c < dim4) { float4 x = g[c]; acc[v].x += x.x; acc[v].y += x.y; acc[v].z += x.z; acc[v].w += x.w; }
+    // A partition larger than the LDS tile holds a row that very many lookups share.  It is walked tile by tile;
+    // a row can then show up in several tiles, so every update of such a partition is an atomic add.
+    const bool multi = cnt > kBwdCap;
+    const int t_end = tile < 255 ? min(cnt, (tile + 1) * kBwdCap) : cnt;
+    for (int t0 = tile * kBwdCap; t0 < t_end; t0 += kBwdCap) {
+        const int n = min(kBwdCap, cnt - t0);
+        int len = 64;
+        while (len < n) len <<= 1;
+        __syncthreads();
+        for (int j = tid; j < len; j += 256) key[j] = j < n ? items[o0 + t0 + j] : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= len; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int c = tid; c < (len >> 1); c += 256) {
+                    const int i = 2 * c - (c & (j - 1)), q = i ^ j;
+                    const unsigned long long a = key[i], b = key[q];
+                    if ((a > b) == ((i & k) == 0)) { key[i] = b; key[q] = a; }
+                }
+                __syncthreads();
             }
-            ++e;
         }
-        // does the segment continue outside this chunk?
-        const bool open = (s == begin && begin > 0 && keys[begin - 1] == key) || (e == end && end < total && keys[end] == key);
-        float *row;
-        if (key < (uint32_t)hotn) {
-            row = w_hot + (size_t)key * dim;
-        } else {
-            const int f = fields ? fields[vals[s]] : (int)(vals[s] / (uint32_t)batch);
-            row = w_cold[f] + (size_t)((int64_t)(key - (uint32_t)hotn) - cold_base[f]) * dim;
-        }
+        // each lane group owns a contiguous range of the sorted tile and carries its sum from chunk to chunk, so a
+        // row with thousands of lookups costs one update per group, not one per chunk
+        const int span = ((n + G - 1) / G + kBwdCH - 1) / kBwdCH * kBwdCH;
+        const int rbegin = grp * span, rend = min(rbegin + span, n);
+        float4 acc[VPL];
 #pragma unroll
-        for (int v = 0; v < MAXV; ++v) {
-            int c = lig + v * LPG;
-            if (c < dim4) {
-                if (open) {
-                    float *r = row + c * 4;
-                    atomicAdd(r + 0, -lr * acc[v].x); atomicAdd(r + 1, -lr * acc[v].y);
-                    atomicAdd(r + 2, -lr * acc[v].z); atomicAdd(r + 3, -lr * acc[v].w);
-                } else {
-                    float4 *r = reinterpret_cast<float4 *>(row) + c;
-                    float4 w = *r;
-                    w.x -= lr * acc[v].x; w.y -= lr * acc[v].y; w.z -= lr * acc[v].z; w.w -= lr * acc[v].w;
-                    *r = w;
+        for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int seg_start = rbegin;
+        for (int begin = rbegin; begin < rend; begin += kBwdCH) {
+            const int end = min(begin + kBwdCH, rend);
+            float4 gr[kBwdCH][VPL];
+#pragma unroll
+            for (int e = 0; e < kBwdCH; ++e) {
+                const uint32_t i = (uint32_t)key[min(begin + e, n - 1)];
+                const float4 *g = reinterpret_cast<const float4 *>(grad + (size_t)i * dim);
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                    const int c = lig + v * LPG;
+                    gr[e][v] = (begin + e < end && c < dim4) ? g[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < kBwdCH; ++e) {
+                if (begin + e < end) {
+                    const uint32_t k = (uint32_t)(key[begin + e] >> 32);
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v) {
+                        acc[v].x += gr[e][v].x; acc[v].y += gr[e][v].y; acc[v].z += gr[e][v].z; acc[v].w += gr[e][v].w;
+                    }
+                    const bool last = begin + e + 1 == rend || (uint32_t)(key[begin + e + 1] >> 32) != k;
+                    if (last) {
+                        const bool open = multi ||
+                                          (seg_start == rbegin && rbegin > 0 && (uint32_t)(key[rbegin - 1] >> 32) == k) ||
+                                          (begin + e + 1 == rend && rend < n && (uint32_t)(key[rend] >> 32) == k);
+                        float *row = row_ptr(k, (uint32_t)key[begin + e], fields, w_hot, w_cold, cold_base, hotn, batch, dim);
+#pragma unroll
+                        for (int v = 0; v < VPL; ++v) {
+                            const int c = lig + v * LPG;
+                            if (c < dim4) {
+                                if (open) {
+                                    float *r = row + c * 4;
+                                    atomicAdd(r + 0, -lr * acc[v].x); atomicAdd(r + 1, -lr * acc[v].y);
+                                    atomicAdd(r + 2, -lr * acc[v].z); atomicAdd(r + 3, -lr * acc[v].w);
+                                } else {
+                                    float4 *r = reinterpret_cast<float4 *>(row) + c;
+                                    float4 w = *r;
+                                    w.x -= lr * acc[v].x; w.y -= lr * acc[v].y; w.z -= lr * acc[v].z; w.w -= lr * acc[v].w;
+                                    *r = w;
+                                }
+                            }
+                            acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                        seg_start = begin + e + 1;
+                    }
                 }
             }
         }
-        s = e;
     }
 }
 
@@ -344,35 +456,44 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     if (total <= 0) return 0;
     const int64_t rows = (int64_t)t->hotn + t->total_cold_rows;
     if (rows >= (int64_t)0xFFFFFFFFLL) { set_error("cafe_backward_sgd_dev: more than 2^32 table rows"); return 1; }
-    if (t->ws_bwd_a.reserve((size_t)total * 4) || t->ws_bwd_b.reserve((size_t)total * 4) ||
-        t->ws_bwd_c.reserve((size_t)total * 4) || t->ws_bwd_d.reserve((size_t)total * 4)) return 1;
-    uint32_t *k0 = t->ws_bwd_a.as<uint32_t>(), *v0 = t->ws_bwd_b.as<uint32_t>();
-    uint32_t *k1 = t->ws_bwd_c.as<uint32_t>(), *v1 = t->ws_bwd_d.as<uint32_t>();
-    hipLaunchKernelGGL(k_row_keys, dim3((total + 255) / 256), dim3(256), 0, st, d_fields, d_que, t->d_hash_size,
-                       t->d_cold_base, t->hotn, batch, total, k0, v0);
-    int bits = 1;
-    while (bits < 32 && ((int64_t)1 << bits) < rows) ++bits;
-    size_t tmp = 0;
-    CAFE_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp, k0, k1, v0, v1, (size_t)total, 0, bits, st));
-    if (t->ws_misc.reserve(tmp + 256)) return 1;
-    CAFE_HIP_CHECK(rocprim::radix_sort_pairs(t->ws_misc.p, tmp, k0, k1, v0, v1, (size_t)total, 0, bits, st));
     const int lpg = lanes_per_row(t->dim);
-    if (t->dim > lpg * 16) { set_error("cafe_backward_sgd_dev: dim %d too large", t->dim); return 1; }
-    constexpr int CH = 16;
-    const int chunks = (total + CH - 1) / CH;
-    const long threads = (long)chunks * lpg;
-    const int blocks = (int)((threads + 255) / 256);
-#define CAFE_SEG(L)                                                                                               \
-    hipLaunchKernelGGL((k_segment_sgd<L, CH>), dim3(blocks), dim3(256), 0, st, k1, v1, d_fields, d_grad_out, t->d_w_hot, \
-                       t->d_w_cold, t->d_cold_base, t->hotn, batch, total, t->dim, lr)
-    switch (lpg) {
-        case 1: CAFE_SEG(1); break;
-        case 2: CAFE_SEG(2); break;
-        case 4: CAFE_SEG(4); break;
-        case 8: CAFE_SEG(8); break;
-        case 16: CAFE_SEG(16); break;
-        case 32: CAFE_SEG(32); break;
-        default: CAFE_SEG(64); break;
+    const int vpl = (t->dim / 4 + lpg - 1) / lpg;
+    if (vpl > 4) { set_error("cafe_backward_sgd_dev: dim %d too large", t->dim); return 1; }
+    int P = std::max(1, std::min((total + kBwdTarget - 1) / kBwdTarget, kBwdMaxBins));
+    const size_t cnt_bytes = 4 * (size_t)kBwdMaxBins + 16;
+    if (t->ws_bwd_a.cap < cnt_bytes) {                      // partition counters: zero once, kept zero by the scatter pass
+        if (t->ws_bwd_a.reserve(cnt_bytes)) return 1;
+        CAFE_HIP_CHECK(hipMemset(t->ws_bwd_a.p, 0, t->ws_bwd_a.cap));
+    }
+    const int max_tiles = P + total / kBwdCap + 1;
+    if (t->ws_bwd_b.reserve(4 * (size_t)kBwdMaxBins + 16) || t->ws_norm.reserve(0) || t->ws_misc.reserve(4 * (size_t)max_tiles + 16) ||
+        t->ws_bwd_c.reserve(8 * (size_t)total) ||
+        t->ws_bwd_d.reserve(8 * (size_t)total)) return 1;
+    uint32_t *cnt = t->ws_bwd_a.as<uint32_t>(), *off = t->ws_bwd_b.as<uint32_t>();
+    uint32_t *rank = t->ws_bwd_c.as<uint32_t>(), *keys = rank + total;
+    unsigned long long *items = t->ws_bwd_d.as<unsigned long long>();
+    hipLaunchKernelGGL(k_bwd_assign, dim3((total + kBwdChunk - 1) / kBwdChunk), dim3(1024), 4 * (size_t)P, st, P, d_fields, d_que,
+                       t->d_hash_size, t->d_cold_base, t->hotn, batch, total, cnt, rank, keys);
+    uint32_t *tiles = t->ws_misc.as<uint32_t>();
+    hipLaunchKernelGGL(k_bwd_offsets, dim3(1), dim3(1024), 0, st, P, cnt, off, tiles);
+    hipLaunchKernelGGL(k_bwd_scatter, dim3((std::max(total, P) + 255) / 256), dim3(256), 0, st, P, total, keys, rank, off, cnt, items);
+#define CAFE_SEG(L, V)                                                                                                   \
+    hipLaunchKernelGGL((k_bwd_segments<L, V>), dim3(max_tiles), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
+                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr)
+    if (vpl == 1) {
+        switch (lpg) {
+            case 1: CAFE_SEG(1, 1); break;
+            case 2: CAFE_SEG(2, 1); break;
+            case 4: CAFE_SEG(4, 1); break;
+            case 8: CAFE_SEG(8, 1); break;
+            case 16: CAFE_SEG(16, 1); break;
+            case 32: CAFE_SEG(32, 1); break;
+            default: CAFE_SEG(64, 1); break;
+        }
+    } else if (vpl == 2) {
+        CAFE_SEG(64, 2);
+    } else {
+        CAFE_SEG(64, 4);
     }
 #undef CAFE_SEG
     CAFE_HIP_CHECK(hipGetLastError());
@@ -388,4 +509,16 @@ extern "C" int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, co
 extern "C" int cafe_backward_sgd_gid_dev(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que,
                                          const float *d_grad_out, int n, float lr, cafe_stream_t stream) {
     return backward_common(t, d_fields, d_que, d_grad_out, 1, n, lr, (hipStream_t)stream);
+}
+
+// scores -> one batch_insert_val over all fields -> migration -> backward + SGD, in the reference's order
+// (dlrm_s_pytorch.py:1642-1658), as one host call: at this point the host side is the bottleneck, not the GPU.
+extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
+                                        const int32_t *d_que, const float *d_grad_out, int batch, float lr, float *d_scores,
+                                        int32_t *d_ins, cafe_stream_t stream) {
+    const int total = t->num_fields * batch;
+    if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
+    if (cafe_insert_dev(s, d_gids, d_scores, total, d_ins, stream)) return 1;
+    if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, 0, t->num_fields, stream)) return 1;
+    return cafe_backward_sgd_dev(t, d_gids, d_que, d_grad_out, batch, lr, stream);
 }

@@ -129,6 +129,12 @@ int cafe_migrate_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_
 int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_que, const float *d_grad_out,
                           int batch, float lr, cafe_stream_t stream);
 
+/* The four calls above in the reference's order (scores, ONE batch_insert_val over all fields' ids in field-major
+ * order, migration, backward + SGD) behind one host call; d_scores / d_ins [num_fields*batch] are outputs. */
+int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
+                             const int32_t *d_que, const float *d_grad_out, int batch, float lr, float *d_scores,
+                             int32_t *d_ins, cafe_stream_t stream);
+
 /* ---- the same four steps for lookups in arbitrary order (each with its own field index), which is what
  *      a shard owner receives from its peers in the multi-GPU path (no reference
  *      counterpart: the reference is single-device).  local id = gid - id_offset[field]. ---- */
