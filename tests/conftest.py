@@ -14,7 +14,13 @@ def pytest_configure(config):
 
 def golden_names():
     g = os.path.join(ROOT, "tests", "golden")
-    return sorted(f[:-4] for f in os.listdir(g) if f.endswith(".npz"))
+    return sorted(f[:-4] for f in os.listdir(g) if f.endswith(".npz") and not f.startswith("module_"))
+
+
+def module_golden_names():
+    """Module-level steps recorded from the reference's SKEmbeddingBag (tests/golden/make_module_golden.py)."""
+    g = os.path.join(ROOT, "tests", "golden")
+    return sorted(f[:-4] for f in os.listdir(g) if f.endswith(".npz") and f.startswith("module_"))
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,82 @@
+"""GPU parity of cafe_amd.sk_embedding_bag.SKEmbeddingBag against steps recorded from the reference's own
+tricks/sk_embedding_bag.py module on CPU (tests/golden/module_*.npz): same constructor, same call order
+(forward of every field -> backward -> insert_grad of every field -> torch.optim.SGD.step), bound to
+libcafe_hip.so the way the reference binds sklib.so (ctypes.CDLL + lib.init).
+
+Bars: routing bit-exact, forward rows / loss / tables within 1e-5 relative (north_star tolerance)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import module_golden_names
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def _close(a, b, what):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert err <= RTOL, f"{what}: max rel err {err:.3e}"
+
+
+def test_module_fails_loudly_without_init():
+    import cafe_amd
+    from cafe_amd import _lib
+    from cafe_amd.sk_embedding_bag import SKEmbeddingBag
+
+    class NoLib:
+        pass
+    L = _lib.load()
+    if L.cafe_global_sketch():
+        pytest.skip("a global sketch already exists in this process")
+    e = SKEmbeddingBag(0, 100, NoLib(), torch.zeros(100, 16, device="cuda"), "cuda", 10, 16, 0, 3).cuda()
+    with pytest.raises(_lib.CafeError):
+        e(torch.arange(4), torch.arange(4))
+
+
+@pytest.mark.parametrize("name", module_golden_names())
+def test_module_matches_reference_module(name):
+    import cafe_amd
+    from cafe_amd.sk_embedding_bag import SKEmbeddingBag, get_sketch_time, reset_sketch_time
+    g = gu.load(name)
+    counts, hs, offs = g["counts"], [int(h) for h in g["hash_sizes"]], g["offsets"]
+    F, D, hotn, B, lr = len(counts), int(g["dim"]), int(g["hotn"]), int(g["batch"]), float(g["lr"])
+    dev = torch.device("cuda", 0)
+    lib = ctypes.CDLL(cafe_amd.LIB_PATH)                                   # dlrm_s_pytorch.py:1403
+    lib.init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    lib.init(hotn, int(g["thr"]), 1, float(g["alpha"]))                    # dlrm_s_pytorch.py:444-449
+    weight_high = torch.nn.Parameter(torch.zeros(hotn, D, device=dev))
+    embs = [SKEmbeddingBag(f, hotn, lib, weight_high, dev, int(counts[f]), D, int(offs[f]), hs[f]) for f in range(F)]
+    for f, e in enumerate(embs):
+        e.to(dev)
+        with torch.no_grad():
+            e.weight_hash.copy_(torch.from_numpy(g[f"w_cold0_{f}"]))
+    opt = torch.optim.SGD([weight_high] + [e.weight_hash for e in embs], lr=lr)
+    A = torch.from_numpy(g["A"]).to(dev)
+    offsets_t = torch.arange(B)
+    reset_sketch_time()
+    for step in range(int(g["steps"])):
+        ids = g[f"ids_{step}"]
+        opt.zero_grad(set_to_none=True)
+        outs = [embs[f](torch.from_numpy(ids[f]), offsets_t) for f in range(F)]       # CPU ids, like the reference
+        for f in range(F):
+            _close(outs[f].detach().cpu().numpy(), g[f"out_{step}"][f], f"{name} step {step} field {f} forward")
+        loss = sum(torch.sigmoid((outs[f] * A[f]).sum(1)).sum() for f in range(F))
+        loss.backward()
+        assert abs(loss.item() - float(g[f"loss_{step}"])) <= RTOL * abs(float(g[f"loss_{step}"]))
+        for f in range(F):
+            embs[f].insert_grad(torch.from_numpy(ids[f]))
+        opt.step()
+        for f in range(F):
+            hot, dic = embs[f].query(torch.from_numpy(ids[f]))
+            want = g[f"que_after_{step}"][f]
+            assert np.array_equal(hot.numpy(), want < 0) and np.array_equal(dic.numpy(), np.abs(want)), \
+                f"{name} step {step} field {f}: routing after the step"
+            _close(embs[f].weight_hash.detach().cpu().numpy(), g[f"w_cold_{step}_{f}"], f"{name} step {step} cold table {f}")
+        _close(weight_high.detach().cpu().numpy(), g[f"w_hot_{step}"], f"{name} step {step} hot table")
+    assert get_sketch_time() > 0.0
+    assert embs[0].query_dic.dtype == np.bool_ and embs[0].query_dic.shape == (B,)
