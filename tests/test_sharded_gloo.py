@@ -1,0 +1,174 @@
+"""Multi-rank path of cafe_amd.sharded.ShardedCafeEmbedding on CPU: world_size 2 over gloo, with the CPU
+oracle standing in for the owner-side HIP calls (parity at G > 1 is defined per shard --
+shard g must equal an independent sketch fed the sub-stream of lookups routed to g, in source-rank then
+batch order).  What is tested here is the exchange: routing by owner, the two all-to-alls and their inverse
+permutation, the all-reduced score normalisation over the global batch, and the order of each shard's sub-stream."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleShardBackend:
+    """Owner-side compute on the CPU oracle (test double of cafe_amd.sharded.HipShardBackend)."""
+
+    def __init__(self, om, counts, dim, hotn, hash_sizes, offsets, threshold, seed):
+        self.om = om
+        self.device = torch.device("cpu")
+        self.dim, self.hotn, self.hash_sizes, self.offsets = dim, hotn, hash_sizes, np.asarray(offsets, np.int64)
+        self.sk = om.Oracle(hotn, threshold, 1, 1.0000005, 1)
+        rng = np.random.default_rng(seed)
+        self.w_hot = np.zeros((hotn, dim), np.float32)
+        self.w_cold = [((rng.random((h, dim), dtype=np.float32) * 2 - 1) * np.float32(np.sqrt(1.0 / n))).astype(np.float32)
+                       for n, h in zip(counts, hash_sizes)]
+        self.stream = []                 # (gid, score) in the order this shard's sketch saw them
+
+    def _rows(self, que, fields):
+        out = np.empty((len(que), self.dim), np.float32)
+        for i, (q, f) in enumerate(zip(que.tolist(), fields.tolist())):
+            out[i] = self.w_hot[-q] if q < 0 else self.w_cold[f][q % self.hash_sizes[f]]
+        return out
+
+    def forward_gid(self, gids, fields):
+        que = self.sk.query(gids.numpy())
+        return torch.from_numpy(que), torch.from_numpy(self._rows(que, fields.numpy()))
+
+    def grad_norm(self, grad, batch):
+        gn = torch.sqrt((grad * grad).sum(-1)).reshape(-1)
+        return gn, gn.view(grad.shape[0], batch).sum(1)
+
+    def backward_gid(self, gids, fields, que, grads, scores, lr):
+        g, f, q = gids.numpy(), fields.numpy(), que.numpy()
+        self.stream.append((g.copy(), scores.numpy().copy()))
+        ins = self.sk.insert_val(g, scores.numpy())
+        qa = self.sk.query(g)
+        for i in np.nonzero(ins)[0]:
+            if qa[i] < 0:
+                local = int(np.int64(g[i]) - self.offsets[f[i]])
+                self.w_hot[-int(qa[i])] = self.w_cold[f[i]][local % self.hash_sizes[f[i]]]
+        gr = grads.numpy()
+        for i in range(len(g)):
+            if q[i] < 0:
+                self.w_hot[-q[i]] -= np.float32(lr) * gr[i]
+            else:
+                self.w_cold[f[i]][q[i] % self.hash_sizes[f[i]]] -= np.float32(lr) * gr[i]
+        return torch.from_numpy(ins)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cafe_amd.sharded import ShardedCafeEmbedding, owner_of, shard_sizes
+        from oracle import cafe_oracle as om
+        counts, hash_sizes, dim, hotn, thr, B, lr = [3000, 40, 50000], [37, 2, 211], 8, 600, 3, 64, 0.1
+        F = len(counts)
+        offsets = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+        lh, lhs = shard_sizes(hotn, hash_sizes, world)
+        be = OracleShardBackend(om, counts, dim, lh, lhs, offsets, thr, seed=100 + rank)
+        eng = ShardedCafeEmbedding(counts, dim, hotn, hash_sizes, offsets, threshold=thr, backend=be)
+        # an independent sketch per shard, fed what the parity definition says the shard must see
+        ref = om.Oracle(lh, thr, 1, 1.0000005, 1)
+        rng = np.random.default_rng(5 + rank)
+        for step in range(6):
+            ids = np.stack([(rng.zipf(1.2, size=B) - 1) % c for c in counts]).astype(np.int64)
+            ids[0] = np.maximum(ids[0], 1)
+            t_ids = torch.from_numpy(ids)
+            out = eng.forward(t_ids)
+            # every rank learns everybody's ids, gradients and tables to check the exchange end to end
+            all_ids = [torch.empty_like(t_ids) for _ in range(world)]
+            dist.all_gather(all_ids, t_ids)
+            gids_all = [(a.numpy() + offsets[:, None]).astype(np.int32).reshape(-1) for a in all_ids]
+            own_all = [owner_of(torch.from_numpy(g), world).numpy() for g in gids_all]
+            # (1) what this shard received = lookups it owns, in (source rank, original position) order
+            want_sub = np.concatenate([g[o == rank] for g, o in zip(gids_all, own_all)])
+            r_gids = eng._saved[4].numpy()
+            assert np.array_equal(r_gids, want_sub), "sub-stream order"
+            # (2) rows came back to the right positions: ask the owner's tables directly
+            tabs = [None] * world
+            dist.all_gather_object(tabs, (be.w_hot.copy(), [w.copy() for w in be.w_cold], be.sk.query(gids_all[rank])))
+            mine, fields = gids_all[rank], np.repeat(np.arange(F), B)
+            grad = torch.from_numpy(np.random.default_rng(1000 * step + rank).standard_normal((F, B, dim)).astype(np.float32))
+            # expected rows via each owner's pre-update tables and its own query result
+            qs = [None] * world
+            for o in range(world):
+                sel = mine[own_all[rank] == o]
+                qs[o] = sel
+            asked = [None] * world
+            dist.all_gather_object(asked, qs)                       # asked[src][owner] = ids src sends to owner
+            answers = [be.sk.query(asked[src][rank]) if len(asked[src][rank]) else np.zeros(0, np.int32) for src in range(world)]
+            got = [None] * world
+            dist.all_gather_object(got, answers)                    # got[owner][src]
+            outv = out.reshape(F * B, dim).numpy()
+            for o in range(world):
+                pos = np.nonzero(own_all[rank] == o)[0]
+                qq = got[o][rank]
+                w_hot_o, w_cold_o, _ = tabs[o]
+                for k, i in enumerate(pos):
+                    f = fields[i]
+                    row = w_hot_o[-qq[k]] if qq[k] < 0 else w_cold_o[f][qq[k] % lhs[f]]
+                    assert np.array_equal(outv[i], row), f"step {step}: row of lookup {i} (owner {o})"
+            scores, ins = eng.backward_update(grad, lr)
+            # (3) scores are normalised over the global batch
+            all_g = [torch.empty_like(grad) for _ in range(world)]
+            dist.all_gather(all_g, grad)
+            gn_all = torch.stack([torch.sqrt((g * g).sum(-1)) for g in all_g])          # [world, F, B]
+            want_sc = gn_all[rank] * (B * world) / gn_all.sum(dim=(0, 2))[:, None]
+            assert torch.allclose(scores.view(F, B), want_sc, rtol=1e-5), "global score normalisation"
+            # (4) the shard's sketch equals an independent sketch fed its sub-stream
+            sub_g, sub_s = be.stream[-1]
+            assert np.array_equal(sub_g, want_sub)
+            want_ins = ref.insert_val(sub_g, sub_s)
+            assert np.array_equal(ins.numpy(), want_ins), "per-shard ins"
+        assert not om.states_equal(be.sk.state(), ref.state())
+        q.put((rank, "ok"))
+    except Exception as e:            # surface the failure in the parent
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sharded_exchange_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+def test_owner_and_shard_sizes():
+    sys.path.insert(0, ROOT)
+    from cafe_amd.sharded import owner_of, shard_sizes
+    g = torch.arange(1, 200001, dtype=torch.int32)
+    for world in (2, 4, 8):
+        o = owner_of(g, world)
+        assert int(o.min()) == 0 and int(o.max()) == world - 1
+        share = torch.bincount(o, minlength=world).double() / g.numel()
+        assert float((share - 1.0 / world).abs().max()) < 0.01          # balanced
+    assert shard_sizes(563200, [1, 7, 3040], 8) == (70400, [1, 1, 380])
+    neg = torch.tensor([-5, -1], dtype=torch.int32)                      # ids >= 2^31 arrive as negative int32
+    assert int(owner_of(neg, 4).min()) >= 0
