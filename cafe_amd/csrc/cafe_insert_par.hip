@@ -24,6 +24,8 @@
 //    (or overflows a workspace, or does not settle in max_rounds) is left untouched and handed to the
 //    in-order kernel.  Nothing is written to the tables before that decision.
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/block/block_radix_sort.hpp>
 
 #include <algorithm>
 
@@ -36,11 +38,11 @@ constexpr int kCapSmall = 2048;   // items an owner of a normal partition sorts 
 constexpr int kCapBig = 8192;     // ... of a partition that holds a heavy id (one workgroup per CU)
 constexpr int kCapEv = 256;       // moves one main partition can receive per round
 constexpr int kCapEvL = 256;      // moves one LRU partition can emit per round
-constexpr int kTargetItems = 128; // average items per partition
+
 constexpr int kMaxBins = 8192;    // partitions per table (LDS histogram of k_assign)
 constexpr int kAssignChunk = 8192;
 constexpr int kMaxRounds = 16;
-constexpr int kHeavySeg = 32;     // a bucket with at least this many items in the batch is replayed by a whole wave
+constexpr int kHeavySeg = 4;      // a bucket with at least this many items in the batch is replayed by a whole wave
 constexpr int kMaxHeavy = 64;     // heavy buckets one partition can hand to its waves (more: replayed by single lanes)
 constexpr int kScanBlock = 1024;
 
@@ -82,27 +84,78 @@ struct ParWorkspace {
 
 struct Geo {
     int n, n1, n2, P1, P2, bpp1, bpp2;
+    int end_bit1, end_bit2;     // one past the highest key bit the owners' sorts have to look at
     FastMod fm1, fm2;
 };
 constexpr size_t kCtlWords = (sizeof(Ctl) + 3) / 4;
 
+// What an owner needs to know about one of its items, written once per call by k_scatter into the item's
+// partition region so that owners read one coalesced stream instead of chasing ids[] / scores[] by position.
+struct __attribute__((aligned(16))) Rec {
+    uint32_t pos;           // batch position
+    uint32_t x;             // id
+    float c;                // score
+    uint32_t bl;            // bucket index inside the partition
+};
+constexpr int kRankSortMax = 256;
+
+// Diagnostic build (make EXTRA=-DCAFE_PROF): wave 0 of every owner stamps the 100 MHz wall clock at phase
+// boundaries of round `CAFE_PROF_ROUND`; tests/diag_stamps.py reads them back.  No code in the normal build.
+#ifdef CAFE_PROF
+#ifndef CAFE_PROF_ROUND
+#define CAFE_PROF_ROUND 1
+#endif
+__device__ unsigned long long g_dbg[2][8192 * 8];
+#define CAFE_STAMP(t, k) do { if (threadIdx.x == 0 && round == CAFE_PROF_ROUND) g_dbg[t][blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#define CAFE_STAMP_VAL(t, k, v) do { if (threadIdx.x == 0 && round == CAFE_PROF_ROUND) g_dbg[t][blockIdx.x * 8 + (k)] = (v); } while (0)
+extern "C" int cafe_debug_read(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg)) != hipSuccess; }
+#else
+#define CAFE_STAMP(t, k) do { } while (0)
+#define CAFE_STAMP_VAL(t, k, v) do { } while (0)
+#endif   // partitions up to this size are sorted by counting smaller keys (one key per lane)
+
 // ------------------------------------------------------------------------------------------------
 // small block-wide helpers
 // ------------------------------------------------------------------------------------------------
-// in-LDS bitonic sort of `len` (power of two) 64-bit keys
-__device__ inline void bitonic_sort(unsigned long long *key, int len) {
-    for (int k = 2; k <= len; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int c = threadIdx.x; c < (len >> 1); c += kThreads) {
-                int i = 2 * c - (c & (j - 1));
-                int p = i ^ j;
-                unsigned long long a = key[i], b = key[p];
-                bool asc = (i & k) == 0;
-                if ((a > b) == asc) { key[i] = b; key[p] = a; }
-            }
-            __syncthreads();
-        }
+// Sort the first `total` 64-bit keys of an LDS array on key bits [begin_bit, end_bit): a workgroup radix sort
+// (rocprim block primitive, 8 bits a pass), instantiated for 2, 4 and CAP/256 keys per lane so that a
+// partition pays for its own size, not for the capacity.  All lanes of the workgroup must call it.
+template <int IPT>
+__device__ inline void block_sort_ipt(unsigned long long *key, int total, int begin_bit, int end_bit, void *storage) {
+    using Sort = rocprim::block_radix_sort<unsigned long long, kThreads, IPT, rocprim::empty_type, 1, 1, 8>;
+    unsigned long long k[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const int j = threadIdx.x * IPT + i;
+        k[i] = j < total ? key[j] : ~0ull;
     }
+    __syncthreads();
+    Sort().sort(k, *reinterpret_cast<typename Sort::storage_type *>(storage), begin_bit, end_bit);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const int j = threadIdx.x * IPT + i;
+        if (j < total) key[j] = k[i];
+    }
+    __syncthreads();
+}
+template <int IPT>
+constexpr size_t sort_bytes() {
+    return sizeof(typename rocprim::block_radix_sort<unsigned long long, kThreads, IPT, rocprim::empty_type, 1, 1, 8>::storage_type);
+}
+constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
+// bytes of the LDS region an owner shares between the sort's scratch and its per-item payload arrays (x, score, flags)
+template <int CAP>
+constexpr size_t pay_bytes() {
+    return (cmax(cmax(cmax(sort_bytes<2>(), sort_bytes<4>()), cmax(sort_bytes<8>(), sort_bytes<(CAP > 2048 ? CAP / kThreads : 8)>())),
+                 (size_t)9 * CAP) + 15) & ~(size_t)15;
+}
+template <int CAP>
+__device__ inline void block_sort(unsigned long long *key, int total, int begin_bit, int end_bit, void *storage) {
+    if (total <= 2 * kThreads) block_sort_ipt<2>(key, total, begin_bit, end_bit, storage);
+    else if (total <= 4 * kThreads) block_sort_ipt<4>(key, total, begin_bit, end_bit, storage);
+    else if (CAP <= 8 * kThreads || total <= 8 * kThreads) block_sort_ipt<8>(key, total, begin_bit, end_bit, storage);
+    else block_sort_ipt<(CAP > 8 * kThreads ? CAP / kThreads : 8)>(key, total, begin_bit, end_bit, storage);
 }
 
 __device__ inline int next_pow2(int v) {
@@ -177,14 +230,34 @@ __global__ void __launch_bounds__(1024) k_offsets(Geo g, const uint32_t *__restr
     if (threadIdx.x == 0 && (long long)st->clk + g.n + 2 >= 0x7fffffffLL) ctl->overflow = 1;
 }
 
-__global__ void k_scatter(Geo g, const int32_t *__restrict__ ids, const uint32_t *__restrict__ off,
-                          const uint32_t *__restrict__ rank1, const uint32_t *__restrict__ rank2,
-                          uint32_t *__restrict__ items1, uint32_t *__restrict__ items2) {
+__global__ void k_scatter(Geo g, const int32_t *__restrict__ ids, const float *__restrict__ scores,
+                          const uint32_t *__restrict__ off, const uint32_t *__restrict__ rank1,
+                          const uint32_t *__restrict__ rank2, Rec *__restrict__ rec1, Rec *__restrict__ rec2) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.n) return;
     const uint32_t x = (uint32_t)ids[i];
-    items1[off[fast_hash(x, g.fm1) / g.bpp1] + rank1[i]] = (uint32_t)i;
-    items2[off[g.P1 + 1 + fast_hash(x, g.fm2) / g.bpp2] + rank2[i]] = (uint32_t)i;
+    const float c = scores ? scores[i] : 1.0f;
+    const int h1 = fast_hash(x, g.fm1), h2 = fast_hash(x, g.fm2);
+    const int p1 = h1 / g.bpp1, p2 = h2 / g.bpp2;
+    Rec r;
+    r.pos = (uint32_t)i; r.x = x; r.c = c;
+    r.bl = (uint32_t)(h1 - p1 * g.bpp1);
+    rec1[off[p1] + rank1[i]] = r;
+    r.bl = (uint32_t)(h2 - p2 * g.bpp2);
+    rec2[off[g.P1 + 1 + p2] + rank2[i]] = r;
+}
+
+// Rank sort of up to kThreads keys, one per lane: the rank of a key is the number of smaller keys (keys are
+// distinct: they contain the batch position).  `key` holds the unsorted keys on entry.
+__device__ inline int rank_of(const unsigned long long *key, int total, unsigned long long mine) {
+    int r = 0;
+    int j = 0;
+    for (; j + 2 <= total; j += 2) {
+        const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(&key[j]);
+        r += (k.x < mine) + (k.y < mine);
+    }
+    if (j < total) r += key[j] < mine;
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -208,15 +281,17 @@ struct MainCtx {
 template <int CAP, bool BIG>
 __global__ void __launch_bounds__(kThreads) k_main_round(
     Geo g, int round, unsigned long long call_tag, const MainBucket *__restrict__ mt, const DevState *__restrict__ st,
-    Ctl *ctl, const int32_t *__restrict__ ids, const float *__restrict__ scores, const uint32_t *__restrict__ off,
-    const uint32_t *__restrict__ items1, const uint32_t *__restrict__ evcnt /* [2][P1] */, const MoveEv *__restrict__ ev,
-    EvRes *__restrict__ evres, uint8_t *__restrict__ miss, uint8_t *__restrict__ outm, MainBucket *__restrict__ stage_m,
-    uint32_t *__restrict__ stage_tot, uint32_t *__restrict__ prevcnt, uint8_t *__restrict__ ldirty /* [2][P2] */) {
-    __shared__ unsigned long long key[CAP];
-    __shared__ uint32_t px[CAP];
-    __shared__ float pc[CAP];
-    __shared__ uint8_t po[CAP];
+    Ctl *ctl, const uint32_t *__restrict__ off, const Rec *__restrict__ rec1, const uint32_t *__restrict__ evcnt /* [2][P1] */,
+    const MoveEv *__restrict__ ev, EvRes *__restrict__ evres, uint8_t *__restrict__ miss, uint8_t *__restrict__ outm,
+    MainBucket *__restrict__ stage_m, uint32_t *__restrict__ stage_tot, uint32_t *__restrict__ prevcnt,
+    uint8_t *__restrict__ ldirty /* [2][P2] */) {
+    __shared__ __attribute__((aligned(16))) unsigned long long key[CAP];
+    __shared__ __attribute__((aligned(16))) unsigned char pay[pay_bytes<CAP>()];     // sort scratch, then x | score | flags
+    uint32_t *px = reinterpret_cast<uint32_t *>(pay);
+    float *pc = reinterpret_cast<float *>(pay + 4 * CAP);
+    uint8_t *po = pay + 8 * CAP;
     __shared__ int heavy[kMaxHeavy];
+    __shared__ __attribute__((aligned(16))) int4 heavy_b[kMaxHeavy][4];      // their table buckets, fetched by phase A
     __shared__ int n_heavy;
 
     if (ctl->final_round || st->fallback || ctl->overflow) return;
@@ -237,6 +312,7 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
     const size_t evold = (size_t)(prev ^ 1) * g.P1 * kCapEv + (size_t)p * kCapEv;     // the moves of the round before
     if (round > 1) {
         const int pne = (int)prevcnt[p];
+        if (ne == 0 && pne == 0) return;             // ran without moves last time, no moves now
         int differ = ne != pne;
         if (!differ) {
             for (int t = tid; t < ne; t += kThreads) {
@@ -258,40 +334,67 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
     }
     if (tid == 0) stage_tot[p] = (uint32_t)total;
     if (total == 0) return;
-    const int len = next_pow2(total);
     const int b0 = p * g.bpp1;
     const int par = round & 1;
+    const Rec *recs = rec1 + o0;
+    CAFE_STAMP(0, 0);
+    CAFE_STAMP_VAL(0, 7, (unsigned long long)total);
 
-    for (int j = tid; j < len; j += kThreads) {
+    // key layout: [bucket in partition : 25][2*position + phase : 23][16 bits: item -> index of its record, move -> index | kind<<15]
+    if (total <= kRankSortMax) {
+        // one entry per lane: everything about it stays in registers while its rank is counted
         unsigned long long k = ~0ull;
-        if (j < np) {
-            uint32_t i = items1[o0 + j];
-            uint32_t bl = (uint32_t)(fast_hash((uint32_t)ids[i], g.fm1) - b0);
-            k = ((unsigned long long)bl << 39) | ((unsigned long long)(2u * i) << 16);
-        } else if (j < total) {
-            int e = j - np;
-            const MoveEv &m = ev[evbase + e];
-            uint32_t bl = (uint32_t)(fast_hash(m.x, g.fm1) - b0);
+        uint32_t x = 0; float c = 0.f; uint8_t pm = 0;
+        if (tid < np) {
+            const Rec r = recs[tid];
+            k = ((unsigned long long)r.bl << 39) | ((unsigned long long)(2u * r.pos) << 16);
+            x = r.x; c = r.c;
+            if (round > 1) pm = miss[r.pos];
+        } else if (tid < total) {
+            const int e = tid - np;
+            const MoveEv m = ev[evbase + e];
+            const uint32_t bl = (uint32_t)(fast_hash(m.x, g.fm1) - b0);
             k = ((unsigned long long)bl << 39) | ((unsigned long long)m.time << 16) | (unsigned)(e | ((m.kind == 1) << 15));
+            x = m.x; c = m.cnt;
         }
-        key[j] = k;
-    }
-    __syncthreads();
-    bitonic_sort(key, len);
-    for (int s = tid; s < total; s += kThreads) {
-        unsigned long long k = key[s];
-        uint32_t time = (uint32_t)(k >> 16) & 0x7fffffu;
-        if (time & 1u) {
-            const MoveEv &m = ev[evbase + (int)(k & 0x7fffu)];
-            px[s] = m.x; pc[s] = m.cnt; po[s] = 0;
-        } else {
-            uint32_t i = time >> 1;
-            px[s] = (uint32_t)ids[i]; pc[s] = scores ? scores[i] : 1.0f;
-            po[s] = round > 1 ? miss[i] : 0;
+        if (tid < ((total + 1) & ~1)) key[tid] = k;
+        __syncthreads();
+        const int r = tid < total ? rank_of(key, total, k) : 0;
+        __syncthreads();
+        if (tid < total) { key[r] = k; px[r] = x; pc[r] = c; po[r] = pm; }
+        __syncthreads();
+    } else {
+        for (int j = tid; j < total; j += kThreads) {
+            unsigned long long k = ~0ull;
+            if (j < np) {
+                const Rec r = recs[j];
+                k = ((unsigned long long)r.bl << 39) | ((unsigned long long)(2u * r.pos) << 16) | (unsigned)j;
+            } else if (j < total) {
+                const int e = j - np;
+                const MoveEv &m = ev[evbase + e];
+                const uint32_t bl = (uint32_t)(fast_hash(m.x, g.fm1) - b0);
+                k = ((unsigned long long)bl << 39) | ((unsigned long long)m.time << 16) | (unsigned)(e | ((m.kind == 1) << 15));
+            }
+            key[j] = k;
         }
+        __syncthreads();
+        block_sort<CAP>(key, total, 16, g.end_bit1, pay);
+        for (int s = tid; s < total; s += kThreads) {
+            const unsigned long long k = key[s];
+            const uint32_t time = (uint32_t)(k >> 16) & 0x7fffffu;
+            if (time & 1u) {
+                const MoveEv &m = ev[evbase + (int)(k & 0x7fffu)];
+                px[s] = m.x; pc[s] = m.cnt; po[s] = 0;
+            } else {
+                const Rec r = recs[(int)(k & 0xffffu)];
+                px[s] = r.x; pc[s] = r.c;
+                po[s] = round > 1 ? miss[r.pos] : 0;
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
+    CAFE_STAMP(0, 1);
     const float thr = st->thr;
     const uint32_t gflip = (uint32_t)st->flip;
     MainBucket *stage = stage_m + o0 + (size_t)p * kCapEv;
@@ -305,11 +408,19 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
         if (s != 0 && (uint32_t)(key[s - 1] >> 39) == bl) continue;
         if (s + kHeavySeg <= total && (uint32_t)(key[s + kHeavySeg - 1] >> 39) == bl) {
             int at = atomicAdd(&n_heavy, 1);
-            if (at < kMaxHeavy) { heavy[at] = s; continue; }
+            if (at < kMaxHeavy) {
+                const int4 *src = reinterpret_cast<const int4 *>(&mt[b0 + (int)bl]);
+                heavy[at] = s;
+                heavy_b[at][0] = src[0]; heavy_b[at][1] = src[1]; heavy_b[at][2] = src[2]; heavy_b[at][3] = src[3];
+                continue;
+            }
         }
         MainR b;
         load_main(b, &mt[b0 + (int)bl]);
         sync_flip(b, gflip);
+#ifdef CAFE_PROF
+        if (s == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CAFE_STAMP(0, 5); }
+#endif
         for (int e = s; e < total && (uint32_t)(key[e] >> 39) == bl; ++e) {
             const unsigned long long k = key[e];
             const uint32_t time = (uint32_t)(k >> 16) & 0x7fffffu;
@@ -317,7 +428,7 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
                 ctx.pos = time >> 1; ctx.flags = 0;
                 int r = main_probe(b, px[e], pc[e], thr, ctx);
                 const bool m = r < 0;
-                if (m != (po[e] != 0)) { changed = 1; ldirty[par * g.P2 + fast_hash(px[e], g.fm2) / g.bpp2] = 1; }
+                if (m != (po[e] != 0)) { changed = 1; if (round > 1) ldirty[par * g.P2 + fast_hash(px[e], g.fm2) / g.bpp2] = 1; }
                 po[e] = (uint8_t)(ctx.flags | (m ? oMiss : 0) | (r > 0 ? oGot : 0));
             } else {
                 ctx.pushed = 0;
@@ -328,9 +439,14 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
                 evres[time >> 1] = r;
             }
         }
+#ifdef CAFE_PROF
+        if (s == 0) CAFE_STAMP(0, 6);
+#endif
         store_main(&stage[s], b, b0 + (int)bl);
     }
     __syncthreads();
+    CAFE_STAMP(0, 2);
+    CAFE_STAMP_VAL(0, 7, (unsigned long long)total | ((unsigned long long)n_heavy << 32));
     // Phase B: heavy buckets, one per wave at a time.  All 64 lanes carry the same bucket copy.  A run of
     // consecutive probes of one id that sits in the bucket only needs the ordered float sum of the scores on
     // the serial path (one readlane + add per item); threshold crossing and the pop are then evaluated for 64
@@ -342,7 +458,7 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
             const int s = heavy[h];
             const uint32_t bl = (uint32_t)(key[s] >> 39);
             MainR b;
-            load_main(b, &mt[b0 + (int)bl]);
+            load_main(b, reinterpret_cast<const MainBucket *>(&heavy_b[h][0]));
             sync_flip(b, gflip);
             int e = s;
             while (e < total && (uint32_t)(key[e] >> 39) == bl) {
@@ -351,6 +467,56 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
                 const uint32_t x0 = px[e];
                 const int hit = (time0 & 1u) ? -1 : find_slot(b, x0);
                 if (hit >= 0) {
+                    // A hot entry far enough above the threshold cannot register a crossing or a pop in a run of
+                    // probes of its own id (with scores >= 0 the score only grows, and fl(fl(a + c) - c) >=
+                    // a - ulp(a + c)): only the ordered sum is needed.  The run may be thousands of items long (a
+                    // heavy id): its length, a bound of its sum and the test are taken 64 items at a time, then
+                    // every lane walks the same chain of adds with the scores streamed from LDS.
+                    if (sel4(b.d0, b.d1, b.d2, b.d3, hit) != 0) {
+                        int r = 0;
+                        float part = 0.0f;
+                        int flag = 0;                      // bit 0: a score is negative or NaN, bit 1: an item missed last round
+                        for (int at = e;; at += 64) {
+                            const int idx = at + lane;
+                            const bool in = idx < total;
+                            const unsigned long long kk = in ? key[idx] : ~0ull;
+                            const bool same = in && (uint32_t)(kk >> 39) == bl && !((uint32_t)(kk >> 16) & 1u) && px[idx] == x0;
+                            const unsigned long long m = __ballot(same);
+                            const int rr = (~m) ? __builtin_ctzll(~m) : 64;
+                            if (lane < rr) {
+                                const float c = pc[idx];
+                                part += c;
+                                flag |= (c >= 0.0f ? 0 : 1) | (po[idx] != 0 ? 2 : 0);
+                            }
+                            r += rr;
+                            if (rr < 64) break;
+                        }
+                        for (int o = 32; o > 0; o >>= 1) { part += __shfl_xor(part, o, 64); flag |= __shfl_xor(flag, o, 64); }
+                        float acc = sel4f(b.c0, b.c1, b.c2, b.c3, hit);
+                        if (!(flag & 1) && acc - (acc + part) * 2.4e-7f >= thr) {
+                            const float *cs = pc + e;
+                            int j = 0;
+                            if (r >= 8) {
+                                float n0 = cs[0], n1 = cs[1], n2 = cs[2], n3 = cs[3], n4 = cs[4], n5 = cs[5], n6 = cs[6], n7 = cs[7];
+                                for (; j + 16 <= r; j += 8) {
+                                    const float c0 = n0, c1 = n1, c2 = n2, c3 = n3, c4 = n4, c5 = n5, c6 = n6, c7 = n7;
+                                    n0 = cs[j + 8]; n1 = cs[j + 9]; n2 = cs[j + 10]; n3 = cs[j + 11];
+                                    n4 = cs[j + 12]; n5 = cs[j + 13]; n6 = cs[j + 14]; n7 = cs[j + 15];
+                                    acc += c0; acc += c1; acc += c2; acc += c3; acc += c4; acc += c5; acc += c6; acc += c7;
+                                }
+                                acc += n0; acc += n1; acc += n2; acc += n3; acc += n4; acc += n5; acc += n6; acc += n7;
+                                j += 8;
+                            }
+                            for (; j < r; ++j) acc += cs[j];
+                            if (flag & 2) {
+                                if (lane == 0) { changed = 1; if (round > 1) ldirty[par * g.P2 + fast_hash(x0, g.fm2) / g.bpp2] = 1; }
+                            }
+                            for (int i = lane; i < r; i += 64) po[e + i] = 0;
+                            CAFE_SET4(b.c0, b.c1, b.c2, b.c3, hit, acc);
+                            e += r;
+                            continue;
+                        }
+                    }
                     const int idx = e + lane;
                     const bool in = idx < total;
                     const unsigned long long kk = in ? key[idx] : ~0ull;
@@ -358,12 +524,12 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
                     const unsigned long long m = __ballot(same);
                     const int r = (~m) ? __builtin_ctzll(~m) : 64;            // length of the run starting at e (>= 1)
                     const float c = in ? pc[idx] : 0.0f;
+                    const bool act = lane < r;
                     float acc = sel4f(b.c0, b.c1, b.c2, b.c3, hit), mine = 0.0f;
                     for (int j = 0; j < r; ++j) {
                         acc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), j));
                         mine = lane == j ? acc : mine;
                     }
-                    const bool act = lane < r;
                     const bool cross = act && mine >= thr && mine - c < thr;
                     int32_t dic = sel4(b.d0, b.d1, b.d2, b.d3, hit);
                     const unsigned long long pm = (!dic && ctx.full) ? __ballot(act && mine >= thr) : 0ull;
@@ -373,7 +539,7 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
                         dic = (int32_t)(kSur | (tpop >> 1));
                     }
                     if (act) {
-                        if (po[idx] != 0) { changed = 1; ldirty[par * g.P2 + fast_hash(x0, g.fm2) / g.bpp2] = 1; }   // it missed last round
+                        if (po[idx] != 0) { changed = 1; if (round > 1) ldirty[par * g.P2 + fast_hash(x0, g.fm2) / g.bpp2] = 1; }   // it missed last round
                         po[idx] = (uint8_t)((cross ? oCross : 0) | (lane == kpop ? (oPop | oGot) : 0));
                     }
                     CAFE_SET4(b.c0, b.c1, b.c2, b.c3, hit, acc);
@@ -381,7 +547,7 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
                     e += r;
                 } else if (!(time0 & 1u)) {
                     if (lane == 0) {
-                        if (po[e] == 0) { changed = 1; ldirty[par * g.P2 + fast_hash(x0, g.fm2) / g.bpp2] = 1; }
+                        if (po[e] == 0) { changed = 1; if (round > 1) ldirty[par * g.P2 + fast_hash(x0, g.fm2) / g.bpp2] = 1; }
                         po[e] = oMiss;
                     }
                     e += 1;
@@ -401,6 +567,7 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
         }
     }
     __syncthreads();
+    CAFE_STAMP(0, 3);
     // parallel write-back of the per-item outcomes; entries that are not a bucket's first item are marked unused
     for (int s = tid; s < total; s += kThreads) {
         const unsigned long long k = key[s];
@@ -415,6 +582,7 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
             reinterpret_cast<int32_t *>(&stage[s])[13] = -1;         // tag word of store_main
     }
     if (changed) atomicOr(&ctl->changed[round], 1u);
+    CAFE_STAMP(0, 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -432,17 +600,21 @@ struct LruCtx {
     __device__ void crossed() { flags |= oCross; }
 };
 
+// key layout of an LRU owner: [bucket in partition : 24][position : 24][index of the item's record : 16]
+__device__ inline uint32_t lkey_bl(unsigned long long k) { return (uint32_t)(k >> 40); }
+__device__ inline uint32_t lkey_pos(unsigned long long k) { return (uint32_t)(k >> 16) & 0xffffffu; }
+
 template <int CAP, bool BIG>
 __global__ void __launch_bounds__(kThreads) k_lru_round(
     Geo g, int round, const LruBucket *__restrict__ lt, const DevState *__restrict__ st, Ctl *ctl,
-    const int32_t *__restrict__ ids, const float *__restrict__ scores, const uint32_t *__restrict__ off,
-    const uint32_t *__restrict__ items2, const uint8_t *__restrict__ miss, uint32_t *evcnt, MoveEv *__restrict__ ev,
-    uint8_t *__restrict__ outl, LruBucket *__restrict__ stage_l, uint32_t *__restrict__ stage_tot,
+    const uint32_t *__restrict__ off, const Rec *__restrict__ rec2, const uint8_t *__restrict__ miss, uint32_t *evcnt,
+    MoveEv *__restrict__ ev, uint8_t *__restrict__ outl, LruBucket *__restrict__ stage_l, uint32_t *__restrict__ stage_tot,
     uint8_t *__restrict__ ldirty /* [2][P2] */, MoveEv *__restrict__ myev /* [P2][kCapEvL] */, uint32_t *__restrict__ mycnt) {
-    __shared__ unsigned long long key[CAP];
-    __shared__ uint32_t px[CAP];
-    __shared__ float pc[CAP];
-    __shared__ uint8_t po[CAP];
+    __shared__ __attribute__((aligned(16))) unsigned long long key[CAP];
+    __shared__ __attribute__((aligned(16))) unsigned char pay[pay_bytes<CAP>()];     // sort scratch, then x | score | flags
+    uint32_t *px = reinterpret_cast<uint32_t *>(pay);
+    float *pc = reinterpret_cast<float *>(pay + 4 * CAP);
+    uint8_t *po = pay + 8 * CAP;
     __shared__ int n_miss, n_ev;
 
     if (ctl->final_round || st->fallback || ctl->overflow) return;
@@ -475,33 +647,59 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
     }
     if (tid == 0) { n_miss = 0; n_ev = 0; }
     __syncthreads();
-    const int len0 = next_pow2(cnt);
     const int b0 = q * g.bpp2;
-    int mine = 0;
-    for (int j = tid; j < len0; j += kThreads) {
+    const Rec *recs = rec2 + o0;
+    int total;
+    CAFE_STAMP(1, 0);
+    if (cnt <= kRankSortMax) {
         unsigned long long k = ~0ull;
-        if (j < cnt) {
-            uint32_t i = items2[o0 + j];
-            if (miss[i]) {
-                uint32_t bl = (uint32_t)(fast_hash((uint32_t)ids[i], g.fm2) - b0);
-                k = ((unsigned long long)bl << 32) | i;
-                ++mine;
+        uint32_t x = 0; float c = 0.f;
+        if (tid < cnt) {
+            const Rec r = recs[tid];
+            if (miss[r.pos]) {
+                k = ((unsigned long long)r.bl << 40) | ((unsigned long long)r.pos << 16);
+                x = r.x; c = r.c;
             }
         }
-        key[j] = k;
+        const unsigned long long mm = __ballot(k != ~0ull);
+        if ((tid & 63) == 0 && mm) atomicAdd(&n_miss, __popcll(mm));
+        if (tid < ((cnt + 1) & ~1)) key[tid] = k;
+        __syncthreads();
+        total = n_miss;
+        if (tid == 0) { stage_tot[g.P1 + q] = (uint32_t)total; if (total == 0) mycnt[q] = 0; }
+        if (total == 0) return;
+        const int r = k != ~0ull ? rank_of(key, cnt, k) : 0;
+        __syncthreads();
+        if (k != ~0ull) { key[r] = k; px[r] = x; pc[r] = c; }
+        __syncthreads();
+    } else {
+        int mine = 0;
+        for (int j = tid; j < cnt; j += kThreads) {
+            unsigned long long k = ~0ull;
+            if (j < cnt) {
+                const Rec r = recs[j];
+                if (miss[r.pos]) {
+                    k = ((unsigned long long)r.bl << 40) | ((unsigned long long)r.pos << 16) | (unsigned)j;
+                    ++mine;
+                }
+            }
+            key[j] = k;
+        }
+        if (mine) atomicAdd(&n_miss, mine);
+        __syncthreads();
+        total = n_miss;
+        if (tid == 0) { stage_tot[g.P1 + q] = (uint32_t)total; if (total == 0) mycnt[q] = 0; }
+        if (total == 0) return;
+        block_sort<CAP>(key, cnt, 16, g.end_bit2, pay);
+        for (int s = tid; s < total; s += kThreads) {
+            const Rec r = recs[(int)(key[s] & 0xffffu)];
+            px[s] = r.x; pc[s] = r.c;
+        }
+        __syncthreads();
     }
-    if (mine) atomicAdd(&n_miss, mine);
-    __syncthreads();
-    const int total = n_miss;
-    if (tid == 0) { stage_tot[g.P1 + q] = (uint32_t)total; if (total == 0) mycnt[q] = 0; }
-    if (total == 0) return;
-    bitonic_sort(key, len0);
-    for (int s = tid; s < total; s += kThreads) {
-        uint32_t i = (uint32_t)key[s];
-        px[s] = (uint32_t)ids[i]; pc[s] = scores ? scores[i] : 1.0f;
-    }
-    __syncthreads();
 
+    CAFE_STAMP(1, 1);
+    CAFE_STAMP_VAL(1, 7, (unsigned long long)total);
     const float thr = st->thr;
     const uint32_t gflip = (uint32_t)st->flip;
     LruBucket *stage = stage_l + o0;
@@ -510,13 +708,13 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
     ctx.clk0 = st->clk;
     int over = 0;
     for (int s = tid; s < total; s += kThreads) {
-        const uint32_t bl = (uint32_t)(key[s] >> 32);
-        if (s != 0 && (uint32_t)(key[s - 1] >> 32) == bl) continue;
+        const uint32_t bl = lkey_bl(key[s]);
+        if (s != 0 && lkey_bl(key[s - 1]) == bl) continue;
         LruR b;
         load_lru(b, &lt[b0 + (int)bl]);
         sync_flip(b, gflip);
-        for (int e = s; e < total && (uint32_t)(key[e] >> 32) == bl; ++e) {
-            const uint32_t pos = (uint32_t)key[e];
+        for (int e = s; e < total && lkey_bl(key[e]) == bl; ++e) {
+            const uint32_t pos = lkey_pos(key[e]);
             const uint32_t x = px[e];
             const float c = pc[e];
             ctx.pos = pos; ctx.flags = 0;
@@ -543,13 +741,15 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
         store_lru(&stage[s], b, b0 + (int)bl);
     }
     __syncthreads();
+    CAFE_STAMP(1, 2);
     if (tid == 0) mycnt[q] = (uint32_t)min(n_ev, kCapEvL);
     for (int s = tid; s < total; s += kThreads) {
-        outl[(uint32_t)key[s]] = po[s];
-        if (s != 0 && (uint32_t)(key[s - 1] >> 32) == (uint32_t)(key[s] >> 32))
+        outl[lkey_pos(key[s])] = po[s];
+        if (s != 0 && lkey_bl(key[s - 1]) == lkey_bl(key[s]))
             reinterpret_cast<int32_t *>(&stage[s])[17] = -1;         // tag word of store_lru
     }
     if (over) ctl->overflow = 1;
+    CAFE_STAMP(1, 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -723,8 +923,8 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, MainBucket *mt, LruBucket
 // ------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------
-static void pick_parts(int n, int buckets, int &P, int &bpp) {
-    int want = std::max(1, (n + kTargetItems - 1) / kTargetItems);
+static void pick_parts(int n, int buckets, int target, int &P, int &bpp) {
+    int want = std::max(1, (n + target - 1) / target);
     P = std::min(std::min(want, buckets), kMaxBins);
     bpp = (buckets + P - 1) / P;
     P = (buckets + bpp - 1) / bpp;
@@ -734,14 +934,17 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     if (!s->par) s->par = new ParWorkspace();
     ParWorkspace &w = *s->par;
     g.n = n; g.n1 = s->n1; g.n2 = s->n2;
-    pick_parts(n, s->n1, g.P1, g.bpp1);
-    pick_parts(n, s->n2, g.P2, g.bpp2);
+    pick_parts(n, s->n1, s->opt_target_items, g.P1, g.bpp1);
+    pick_parts(n, s->n2, s->opt_target_items, g.P2, g.bpp2);
     g.fm1 = make_fastmod(s->n1);
     g.fm2 = make_fastmod(s->n2);
+    auto bits = [](int v) { int b = 1; while ((1 << b) < v) ++b; return b; };
+    g.end_bit1 = 39 + bits(g.bpp1);
+    g.end_bit2 = 40 + bits(g.bpp2);
     const size_t N = (size_t)n, PP = (size_t)g.P1 + g.P2;
     const int nblocks = (n + kScanBlock - 1) / kScanBlock;
     if (w.zr.reserve(4 * (kCtlWords + PP + 2 * (size_t)g.P1) + 16) || w.off.reserve(4 * PP + 16) || w.rank.reserve(8 * N) ||
-        w.items.reserve(8 * N) || w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * kCapEv) ||
+        w.items.reserve(2 * sizeof(Rec) * N) || w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * kCapEv) ||
         w.evres.reserve(sizeof(EvRes) * N) || w.miss.reserve(N) || w.outm.reserve(N) || w.outl.reserve(N) ||
         w.stage_m.reserve(sizeof(MainBucket) * (N + (size_t)g.P1 * kCapEv)) || w.stage_l.reserve(sizeof(LruBucket) * N) ||
         w.stage_tot.reserve(4 * PP + 4) || w.prevcnt.reserve(4 * (size_t)g.P1 + 4) || w.ldirty.reserve(2 * (size_t)g.P2 + 4) ||
@@ -800,23 +1003,23 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     uint32_t *cnt = w.zr.as<uint32_t>() + kCtlWords, *evcnt = cnt + g.P1 + g.P2;
     uint32_t *off = w.off.as<uint32_t>();
     uint32_t *rank1 = w.rank.as<uint32_t>(), *rank2 = rank1 + n;
-    uint32_t *items1 = w.items.as<uint32_t>(), *items2 = items1 + n;
+    Rec *rec1 = w.items.as<Rec>(), *rec2 = rec1 + n;
     uint32_t *stage_tot = w.stage_tot.as<uint32_t>();
     const int gb = (n + 255) / 256;
     hipLaunchKernelGGL(k_assign, dim3((n + kAssignChunk - 1) / kAssignChunk), dim3(1024), 4 * (size_t)(g.P1 + g.P2), st, g,
                        d_ids, cnt, rank1, rank2);
     hipLaunchKernelGGL(k_offsets, dim3(2), dim3(1024), 0, st, g, cnt, off, ctl, s->d_state);
-    hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, g, d_ids, off, rank1, rank2, items1, items2);
+    hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, g, d_ids, d_scores, off, rank1, rank2, rec1, rec2);
     int rounds;
     bool big;
     launch_plan(s, n, rounds, big);
 #define CAFE_MAIN(CAPV, BIGV)                                                                                              \
     hipLaunchKernelGGL((k_main_round<CAPV, BIGV>), dim3(g.P1), dim3(kThreads), 0, st, g, r, tag, s->d_main, s->d_state, ctl, \
-                       d_ids, d_scores, off, items1, evcnt, w.ev.as<MoveEv>(), w.evres.as<EvRes>(), w.miss.as<uint8_t>(),    \
+                       off, rec1, evcnt, w.ev.as<MoveEv>(), w.evres.as<EvRes>(), w.miss.as<uint8_t>(),    \
                        w.outm.as<uint8_t>(), w.stage_m.as<MainBucket>(), stage_tot, w.prevcnt.as<uint32_t>(), w.ldirty.as<uint8_t>())
 #define CAFE_LRU(CAPV, BIGV)                                                                                               \
-    hipLaunchKernelGGL((k_lru_round<CAPV, BIGV>), dim3(g.P2), dim3(kThreads), 0, st, g, r, s->d_lru, s->d_state, ctl, d_ids, \
-                       d_scores, off, items2, w.miss.as<uint8_t>(), evcnt, w.ev.as<MoveEv>(), w.outl.as<uint8_t>(),          \
+    hipLaunchKernelGGL((k_lru_round<CAPV, BIGV>), dim3(g.P2), dim3(kThreads), 0, st, g, r, s->d_lru, s->d_state, ctl, \
+                       off, rec2, w.miss.as<uint8_t>(), evcnt, w.ev.as<MoveEv>(), w.outl.as<uint8_t>(),          \
                        w.stage_l.as<LruBucket>(), stage_tot, w.ldirty.as<uint8_t>(), w.myev.as<MoveEv>(), w.mycnt.as<uint32_t>())
     for (int r = 1; r <= rounds; ++r) {
         CAFE_MAIN(kCapSmall, false);

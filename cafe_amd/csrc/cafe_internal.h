@@ -50,7 +50,7 @@ struct cafe_sketch {
     // upper bound of real_n known to the host without a sync (each inserted id raises real_n by at most 1)
     long long real_n_ub = 0;
     // options / counters
-    int opt_serial = 0, opt_max_rounds = 6;
+    int opt_serial = 0, opt_max_rounds = 6, opt_target_items = 224;
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // workspaces
     cafe::DevBuf ws_reset_keys, ws_reset_keys2, ws_reset_tmp, ws_reset_flags, ws_misc;

@@ -369,6 +369,7 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     cafe_sketch *s = new cafe_sketch();
     CAFE_HIP_CHECK(hipGetDevice(&s->device));
     s->lim = lim; s->adjust = adjust_thres; s->alpha = alpha; s->lru_first = lru_first ? 1 : 0;
+    if (const char *e = getenv("CAFE_TARGET_ITEMS")) s->opt_target_items = std::max(16, atoi(e));   // tuning aid
     s->n1 = (int)(lim * 0.9);           // sketch.cpp:51-52
     s->n2 = (int)(lim * 0.1);
     s->fifo_cap = (uint32_t)lim;
@@ -405,6 +406,7 @@ extern "C" int cafe_sketch_destroy(cafe_sketch_t *s) {
 extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int value) {
     if (!strcmp(name, "serial_insert")) s->opt_serial = value;
     else if (!strcmp(name, "max_rounds")) s->opt_max_rounds = value < 1 ? 1 : value;
+    else if (!strcmp(name, "target_items")) s->opt_target_items = value < 16 ? 16 : value;
     else { set_error("unknown option %s", name); return 1; }
     return 0;
 }
