@@ -261,10 +261,10 @@ extern "C" int cafe_migrate_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const in
 // (dlrm_s_pytorch.py:1658).  Here: unified row keys -> sort -> segment sums -> one read-modify-write per
 // touched row.  Segments that cross a chunk border finish with float atomics.
 // ------------------------------------------------------------------------------------------------
-constexpr int kBwdChunk = 8192;     // items per workgroup of the partitioning pass
-constexpr int kBwdCap = 1024;       // items a workgroup sorts in LDS (larger partitions are cut into tiles)
+constexpr int kBwdChunk = 2048;     // items per workgroup of the partitioning pass
+constexpr int kBwdCap = 256;        // items a workgroup sorts in LDS, one per lane (larger partitions are cut into tiles)
 constexpr int kBwdMaxBins = 8192;
-constexpr int kBwdTarget = 256;     // average items per partition
+constexpr int kBwdTarget = 160;     // average items per partition: a partition without a heavy row fits one tile
 constexpr int kBwdCH = 8;           // items a lane group takes at a time
 
 __device__ inline uint32_t row_key(const int32_t *__restrict__ fields, const int32_t *__restrict__ que,
@@ -349,17 +349,41 @@ __device__ inline float *row_ptr(uint32_t key, uint32_t item, const int32_t *__r
     return w_cold[f] + (size_t)((int64_t)(key - (uint32_t)hotn) - cold_base[f]) * dim;
 }
 
-// One workgroup per partition: sort the partition's (row, lookup) pairs in LDS, then lane groups of LPG lanes walk
-// chunks of kBwdCH consecutive pairs: the chunk's gradient rows are fetched together, summed per row in lookup order,
-// and each row gets W -= lr * sum.  A row whose pairs all lie inside one chunk is updated with a plain
-// read-modify-write; a row spread over several chunks finishes with float atomics.
+// One workgroup per (partition, tile): sort the tile's (row, lookup) pairs in LDS, then lane groups of LPG lanes walk
+// contiguous ranges of the sorted tile kBwdCH pairs at a time.  Everything a chunk needs from HBM -- its gradient rows
+// and the table rows of the segments that end inside it -- is requested before anything is used, so a chunk costs one
+// memory round trip, not one per row.  Sums run in lookup order (reproducible); each row gets W -= lr * sum.  A row
+// whose pairs all lie inside one group's range is updated with a plain read-modify-write; a row spread over several
+// groups or tiles finishes with float atomics.
+__device__ inline int bwd_rank_of(const unsigned long long *key, int n, unsigned long long mine) {
+    int r = 0, j = 0;
+    for (; j + 2 <= n; j += 2) {
+        const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(&key[j]);
+        r += (k.x < mine) + (k.y < mine);
+    }
+    if (j < n) r += key[j] < mine;
+    return r;
+}
+
+#ifdef CAFE_PROF
+__device__ unsigned long long g_dbg_bwd[8192 * 8];
+#define BWD_STAMP(k) do { if (threadIdx.x == 0) g_dbg_bwd[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#define BWD_VAL(k, v) do { if (threadIdx.x == 0) g_dbg_bwd[blockIdx.x * 8 + (k)] = (v); } while (0)
+extern "C" int cafe_debug_read_bwd(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_bwd), sizeof(g_dbg_bwd)) != hipSuccess; }
+#else
+#define BWD_STAMP(k) do { } while (0)
+#define BWD_VAL(k, v) do { } while (0)
+#endif
+
 template <int LPG, int VPL>
 __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tiles,
                                                       const unsigned long long *__restrict__ items,
                                                       const int32_t *__restrict__ fields, const float *__restrict__ grad,
                                                       float *__restrict__ w_hot, float *const *__restrict__ w_cold,
                                                       const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr) {
-    __shared__ unsigned long long key[kBwdCap];
+    __shared__ __attribute__((aligned(16))) unsigned long long key[kBwdCap];
+    __shared__ float4 bpart[2][VPL][256];      // border partial sums: [0] head of a group's range, [1] tail
+    __shared__ int bflag[256];
     const int tid = threadIdx.x;
     if (blockIdx.x >= tiles[0]) return;
     // the tile index is kept in 8 bits; a partition with more tiles lets its last workgroup walk the rest
@@ -374,81 +398,147 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
     // a row can then show up in several tiles, so every update of such a partition is an atomic add.
     const bool multi = cnt > kBwdCap;
     const int t_end = tile < 255 ? min(cnt, (tile + 1) * kBwdCap) : cnt;
+    BWD_STAMP(0);
+    BWD_VAL(7, (unsigned long long)cnt);
     for (int t0 = tile * kBwdCap; t0 < t_end; t0 += kBwdCap) {
         const int n = min(kBwdCap, cnt - t0);
-        int len = 64;
-        while (len < n) len <<= 1;
         __syncthreads();
-        for (int j = tid; j < len; j += 256) key[j] = j < n ? items[o0 + t0 + j] : ~0ull;
-        __syncthreads();
-        for (int k = 2; k <= len; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int c = tid; c < (len >> 1); c += 256) {
-                    const int i = 2 * c - (c & (j - 1)), q = i ^ j;
-                    const unsigned long long a = key[i], b = key[q];
-                    if ((a > b) == ((i & k) == 0)) { key[i] = b; key[q] = a; }
-                }
-                __syncthreads();
-            }
+        {
+            // one pair per lane: its rank is the number of smaller pairs (pairs are distinct)
+            const unsigned long long k = tid < n ? items[o0 + t0 + tid] : ~0ull;
+            if (tid < ((n + 1) & ~1)) key[tid] = k;
+            __syncthreads();
+            const int r = tid < n ? bwd_rank_of(key, n, k) : 0;
+            __syncthreads();
+            if (tid < n) key[r] = k;
+            __syncthreads();
         }
-        // each lane group owns a contiguous range of the sorted tile and carries its sum from chunk to chunk, so a
-        // row with thousands of lookups costs one update per group, not one per chunk
+        BWD_STAMP(1);
+        // Each lane group owns a contiguous range of the sorted tile and carries its sum from chunk to chunk.  A row
+        // that lies inside one group's range gets its update there.  A row that crosses group borders is summed through
+        // LDS: every group leaves the partial sum of its border segment(s) in LDS, and the group in whose range the row
+        // starts adds the following groups' partials in order and issues the one update (atomic only if the partition
+        // has several tiles, i.e. the row may also be touched by another workgroup).
         const int span = ((n + G - 1) / G + kBwdCH - 1) / kBwdCH * kBwdCH;
         const int rbegin = grp * span, rend = min(rbegin + span, n);
+        const bool head_same = rbegin > 0 && rbegin < n && (uint32_t)(key[rbegin - 1] >> 32) == (uint32_t)(key[rbegin] >> 32);
+        const bool tail_same = rbegin < rend && rend < n && (uint32_t)(key[rend] >> 32) == (uint32_t)(key[rend - 1] >> 32);
+        if (lig == 0) { bflag[grp] = 0; }
         float4 acc[VPL];
 #pragma unroll
         for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         int seg_start = rbegin;
+        float *lead_row = nullptr;
         for (int begin = rbegin; begin < rend; begin += kBwdCH) {
             const int end = min(begin + kBwdCH, rend);
-            float4 gr[kBwdCH][VPL];
+            float4 gr[kBwdCH][VPL], wr[kBwdCH][VPL];
+            float *rowp[kBwdCH];
+            unsigned mode = 0;       // per item 3 bits: 0 inside a segment, 1 plain update, 2 atomic update, 3 head partial, 4 tail partial
+            int ss = seg_start;
 #pragma unroll
             for (int e = 0; e < kBwdCH; ++e) {
-                const uint32_t i = (uint32_t)key[min(begin + e, n - 1)];
+                const bool live = begin + e < end;
+                const unsigned long long ke = key[min(begin + e, n - 1)];
+                const uint32_t i = (uint32_t)ke, k = (uint32_t)(ke >> 32);
                 const float4 *g = reinterpret_cast<const float4 *>(grad + (size_t)i * dim);
+                bool last = false;
+                unsigned m = 0;
+                if (live) {
+                    last = begin + e + 1 == rend || (uint32_t)(key[begin + e + 1] >> 32) != k;
+                    if (last) {
+                        const bool head = ss == rbegin && head_same, tail = begin + e + 1 == rend && tail_same;
+                        m = head ? 3u : tail ? 4u : multi ? 2u : 1u;
+                        if (head && tail) m = 5u;                    // the whole range is the middle of one row's run
+                        ss = begin + e + 1;
+                    }
+                }
+                rowp[e] = last ? row_ptr(k, i, fields, w_hot, w_cold, cold_base, hotn, batch, dim) : nullptr;
+                mode |= m << (3 * e);
 #pragma unroll
                 for (int v = 0; v < VPL; ++v) {
                     const int c = lig + v * LPG;
-                    gr[e][v] = (begin + e < end && c < dim4) ? g[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    gr[e][v] = (live && c < dim4) ? g[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    wr[e][v] = (m == 1u && c < dim4) ? reinterpret_cast<const float4 *>(rowp[e])[c]
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
+            seg_start = ss;
 #pragma unroll
             for (int e = 0; e < kBwdCH; ++e) {
-                if (begin + e < end) {
-                    const uint32_t k = (uint32_t)(key[begin + e] >> 32);
+                const unsigned m = (mode >> (3 * e)) & 7u;
 #pragma unroll
-                    for (int v = 0; v < VPL; ++v) {
-                        acc[v].x += gr[e][v].x; acc[v].y += gr[e][v].y; acc[v].z += gr[e][v].z; acc[v].w += gr[e][v].w;
-                    }
-                    const bool last = begin + e + 1 == rend || (uint32_t)(key[begin + e + 1] >> 32) != k;
-                    if (last) {
-                        const bool open = multi ||
-                                          (seg_start == rbegin && rbegin > 0 && (uint32_t)(key[rbegin - 1] >> 32) == k) ||
-                                          (begin + e + 1 == rend && rend < n && (uint32_t)(key[rend] >> 32) == k);
-                        float *row = row_ptr(k, (uint32_t)key[begin + e], fields, w_hot, w_cold, cold_base, hotn, batch, dim);
+                for (int v = 0; v < VPL; ++v) {
+                    acc[v].x += gr[e][v].x; acc[v].y += gr[e][v].y; acc[v].z += gr[e][v].z; acc[v].w += gr[e][v].w;
+                }
+                if (m) {
+                    if (m >= 3u) {
+                        // border segment: leave the partial sum in LDS.  Flags: 1 head partial, 2 tail partial (this
+                        // group leads the run), 4 the head partial covers the whole range (the run goes on)
+                        const int slot = m == 4u ? 1 : 0;
+#pragma unroll
+                        for (int v = 0; v < VPL; ++v) bpart[slot][v][tid] = acc[v];
+                        if (m == 4u) lead_row = rowp[e];
+                        if (lig == 0) bflag[grp] |= m == 3u ? 1 : m == 4u ? 2 : 5;
+                    } else {
 #pragma unroll
                         for (int v = 0; v < VPL; ++v) {
                             const int c = lig + v * LPG;
                             if (c < dim4) {
-                                if (open) {
-                                    float *r = row + c * 4;
+                                if (m == 2u) {
+#ifndef CAFE_NO_ATOMIC
+                                    float *r = rowp[e] + c * 4;
                                     atomicAdd(r + 0, -lr * acc[v].x); atomicAdd(r + 1, -lr * acc[v].y);
                                     atomicAdd(r + 2, -lr * acc[v].z); atomicAdd(r + 3, -lr * acc[v].w);
+#endif
                                 } else {
-                                    float4 *r = reinterpret_cast<float4 *>(row) + c;
-                                    float4 w = *r;
+                                    float4 w = wr[e][v];
                                     w.x -= lr * acc[v].x; w.y -= lr * acc[v].y; w.z -= lr * acc[v].z; w.w -= lr * acc[v].w;
-                                    *r = w;
+                                    reinterpret_cast<float4 *>(rowp[e])[c] = w;
                                 }
                             }
-                            acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
                         }
-                        seg_start = begin + e + 1;
+                    }
+#pragma unroll
+                    for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        if (lead_row) {          // uniform over the lane group
+            float4 sum[VPL];
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) sum[v] = bpart[1][v][tid];
+            for (int g2 = grp + 1; g2 < G; ++g2) {
+                const int f = bflag[g2];
+                if (!(f & 1)) break;
+#pragma unroll
+                for (int v = 0; v < VPL; ++v) {
+                    const float4 q = bpart[0][v][g2 * LPG + lig];
+                    sum[v].x += q.x; sum[v].y += q.y; sum[v].z += q.z; sum[v].w += q.w;
+                }
+                if (!(f & 4)) break;
+            }
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                const int c = lig + v * LPG;
+                if (c < dim4) {
+                    if (multi) {
+#ifndef CAFE_NO_ATOMIC
+                        float *r = lead_row + c * 4;
+                        atomicAdd(r + 0, -lr * sum[v].x); atomicAdd(r + 1, -lr * sum[v].y);
+                        atomicAdd(r + 2, -lr * sum[v].z); atomicAdd(r + 3, -lr * sum[v].w);
+#endif
+                    } else {
+                        float4 w = reinterpret_cast<const float4 *>(lead_row)[c];
+                        w.x -= lr * sum[v].x; w.y -= lr * sum[v].y; w.z -= lr * sum[v].z; w.w -= lr * sum[v].w;
+                        reinterpret_cast<float4 *>(lead_row)[c] = w;
                     }
                 }
             }
         }
     }
+    __syncthreads();
+    BWD_STAMP(2);
 }
 
 static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,

@@ -40,7 +40,7 @@ constexpr int kCapEv = 256;       // moves one main partition can receive per ro
 constexpr int kCapEvL = 256;      // moves one LRU partition can emit per round
 
 constexpr int kMaxBins = 8192;    // partitions per table (LDS histogram of k_assign)
-constexpr int kAssignChunk = 8192;
+constexpr int kAssignChunk = 2048;
 constexpr int kMaxRounds = 16;
 constexpr int kHeavySeg = 4;      // a bucket with at least this many items in the batch is replayed by a whole wave
 constexpr int kMaxHeavy = 64;     // heavy buckets one partition can hand to its waves (more: replayed by single lanes)

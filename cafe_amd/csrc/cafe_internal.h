@@ -55,11 +55,12 @@ struct cafe_sketch {
     // workspaces
     cafe::DevBuf ws_reset_keys, ws_reset_keys2, ws_reset_tmp, ws_reset_flags, ws_misc;
     cafe::ParWorkspace *par = nullptr;
-    int32_t *h_pinned = nullptr;    // pinned copy of DevState, refreshed behind every insert (lagging feedback)
+    int32_t *h_pinned = nullptr;    // pinned host mirror of DevState, written by the kernel that closes every insert
+    int32_t *d_pinned = nullptr;    // the same memory as the device sees it
+    hipStream_t last_stream = nullptr;
     int hint_rounds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // final round counts of recent calls (0 = unknown)
     int hint_pos = 0;
     long long last_seen_batch = -1;
-    hipEvent_t ev_real_n = nullptr; // recorded after the async readback of real_n that ends every insert
     bool real_n_pending = false;
 };
 

@@ -144,7 +144,7 @@ struct SerialCtx {
 __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket *lt, uint32_t *fifo, uint32_t cap,
                                                       DevState *st, int n1, int n2, const int32_t *__restrict__ ids,
                                                       const float *__restrict__ scores, int n, int32_t *__restrict__ ins,
-                                                      int only_if_fallback, const uint32_t *par_totals) {
+                                                      int only_if_fallback, const uint32_t *par_totals, DevState *host_mirror) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (only_if_fallback && !st->fallback) {
         // the parallel insert settled: apply its batch totals (pops, pushes, clock ticks, crossings, rounds)
@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket 
         st->real_n += (int32_t)par_totals[3];
         st->pad[1] += (int32_t)par_totals[4];
         if ((int32_t)par_totals[4] > st->pad[2]) st->pad[2] = (int32_t)par_totals[4];
+        *host_mirror = *st;             // pinned host memory: the host reads it lagging, without a copy or a sync
         return;
     }
     if (only_if_fallback) st->pad[0] += 1;          // cumulative: batches handed to the in-order kernel
@@ -199,12 +200,14 @@ __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket 
     }
     st->fifo_head = ctx.head; st->fifo_len = ctx.len;
     st->num = ctx.num; st->real_n = ctx.real_n; st->clk = ctx.clk;
+    *host_mirror = *st;
 }
 
 int cafe::launch_serial_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
                                int only_if_fallback, hipStream_t st, const uint32_t *par_totals) {
     hipLaunchKernelGGL(k_insert_serial, dim3(1), dim3(64), 0, st, s->d_main, s->d_lru, s->d_fifo, s->fifo_cap,
-                       s->d_state, s->n1, s->n2, d_ids, d_scores, n, d_ins, only_if_fallback, par_totals);
+                       s->d_state, s->n1, s->n2, d_ids, d_scores, n, d_ins, only_if_fallback, par_totals,
+                       reinterpret_cast<DevState *>(s->d_pinned));
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -377,9 +380,9 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     CAFE_HIP_CHECK(hipMalloc(&s->d_lru, sizeof(LruBucket) * (size_t)s->n2));
     CAFE_HIP_CHECK(hipMalloc(&s->d_fifo, sizeof(uint32_t) * (size_t)s->fifo_cap));
     CAFE_HIP_CHECK(hipMalloc(&s->d_state, sizeof(DevState)));
-    CAFE_HIP_CHECK(hipHostMalloc((void **)&s->h_pinned, 256, hipHostMallocDefault));
+    CAFE_HIP_CHECK(hipHostMalloc((void **)&s->h_pinned, 256, hipHostMallocMapped));
     memset(s->h_pinned, 0, 256);
-    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_real_n, hipEventDisableTiming));
+    CAFE_HIP_CHECK(hipHostGetDevicePointer((void **)&s->d_pinned, s->h_pinned, 0));
     if (s->ws_misc.reserve(4096)) return 1;
     CAFE_HIP_CHECK(hipMemset(s->d_main, 0, sizeof(MainBucket) * (size_t)s->n1));
     CAFE_HIP_CHECK(hipMemset(s->d_lru, 0, sizeof(LruBucket) * (size_t)s->n2));
@@ -396,7 +399,6 @@ extern "C" int cafe_sketch_destroy(cafe_sketch_t *s) {
     par_free(s);
     (void)hipFree(s->d_main); (void)hipFree(s->d_lru); (void)hipFree(s->d_fifo); (void)hipFree(s->d_state);
     if (s->h_pinned) (void)hipHostFree(s->h_pinned);
-    if (s->ev_real_n) (void)hipEventDestroy(s->ev_real_n);
     s->ws_reset_keys.release(); s->ws_reset_keys2.release(); s->ws_reset_tmp.release();
     s->ws_reset_flags.release(); s->ws_misc.release();
     delete s;
@@ -642,9 +644,9 @@ extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const flo
     // for that copy (normally long done: later kernels of the step were queued behind it) gives the exact value.
     if (s->adjust && (double)s->real_n_ub > s->lim * 1.2) {
         if (s->real_n_pending) {
-            CAFE_HIP_CHECK(hipEventSynchronize(s->ev_real_n));
+            CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));        // rare: only when a reset may be due
             s->real_n_pending = false;
-            s->real_n_ub = reinterpret_cast<const DevState *>(s->h_pinned)->real_n;
+            s->real_n_ub = reinterpret_cast<const volatile DevState *>(s->h_pinned)->real_n;
         }
         if ((double)s->real_n_ub > s->lim * 1.2) {
             if (run_reset(s, st)) return 1;
@@ -662,8 +664,7 @@ extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const flo
     }
     s->real_n_ub += n;        // upper bound until the readback below is consumed
     if (rc == 0) {
-        CAFE_HIP_CHECK(hipMemcpyAsync(s->h_pinned, s->d_state, sizeof(DevState), hipMemcpyDeviceToHost, st));
-        CAFE_HIP_CHECK(hipEventRecord(s->ev_real_n, st));
+        s->last_stream = st;            // the closing kernel mirrors the device state into pinned host memory
         s->real_n_pending = true;
     }
     return rc;
