@@ -71,23 +71,52 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
                                                  int batch, int total, int dim,
                                                  int32_t *__restrict__ gids, int32_t *__restrict__ que,
                                                  float *__restrict__ out) {
-    const int lig = threadIdx.x % LPG;
-    const int groups = (gridDim.x * blockDim.x) / LPG;
+    // A wave takes 64 consecutive lookups.  First every lane resolves one lookup on its own (id, one 32-B probe of
+    // val|dic, routing, source row address): three dependent memory steps for 64 lookups instead of per lookup.  Then
+    // the wave copies the 64 rows, 64/LPG rows per instruction (LPG lanes x float4 = one row), eight instructions in
+    // flight per lane; the source row address travels by cross-lane read.
+    constexpr int RPI = 64 / LPG;                       // rows per wave instruction
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
     const int dim4 = dim >> 2;
-    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) / LPG; i < total; i += groups) {
-        const int f = fields ? fields[i] : i / batch;
-        const int32_t g = local_ids ? (int32_t)(local_ids[i] + id_offset[f]) : in_gids[i];      // sk_embedding_bag.py:103
-        const uint32_t x = (uint32_t)g;
-        const int4 *p = reinterpret_cast<const int4 *>(&mt[fast_hash(x, fm1)]);
-        const int4 v = p[0], d = p[1];
-        const int32_t val[4] = {v.x, v.y, v.z, v.w}, dic[4] = {d.x, d.y, d.z, d.w};
-        const int32_t q = query_bucket(val, dic, x);
-        // hot: W_h[|q| % hotn] = W_h[slot]; cold: W_hash[|q| % hash_size] (sk_embedding_bag.py:134-150)
-        const float *row = q < 0 ? w_hot + (size_t)(-q) * dim
-                                 : w_cold[f] + (size_t)((uint32_t)q % (uint32_t)hash_size[f]) * dim;
-        if (lig == 0) { if (gids) gids[i] = g; que[i] = q; }
-        float4 *o = reinterpret_cast<float4 *>(out + (size_t)i * dim);
-        for (int c = lig; c < dim4; c += LPG) o[c] = reinterpret_cast<const float4 *>(row)[c];
+    const int lig = lane % LPG, sub = lane / LPG;
+    for (int base = wave * 64; base < total; base += waves * 64) {
+        const int i = base + lane;
+        const float *row = nullptr;
+        if (i < total) {
+            const int f = fields ? fields[i] : i / batch;
+            const int32_t g = local_ids ? (int32_t)(local_ids[i] + id_offset[f]) : in_gids[i];      // sk_embedding_bag.py:103
+            const uint32_t x = (uint32_t)g;
+            const int4 *p = reinterpret_cast<const int4 *>(&mt[fast_hash(x, fm1)]);
+            const int4 v = p[0], d = p[1];
+            const int32_t val[4] = {v.x, v.y, v.z, v.w}, dic[4] = {d.x, d.y, d.z, d.w};
+            const int32_t q = query_bucket(val, dic, x);
+            // hot: W_h[|q| % hotn] = W_h[slot]; cold: W_hash[|q| % hash_size] (sk_embedding_bag.py:134-150)
+            row = q < 0 ? w_hot + (size_t)(-q) * dim : w_cold[f] + (size_t)((uint32_t)q % (uint32_t)hash_size[f]) * dim;
+            if (gids) gids[i] = g;
+            que[i] = q;
+        }
+        const unsigned long long ra = (unsigned long long)row;
+        const int lo = (int)(uint32_t)ra, hi = (int)(uint32_t)(ra >> 32);
+        const int nrow = min(64, total - base);
+        float4 *obase = reinterpret_cast<float4 *>(out + (size_t)base * dim);
+        for (int c0 = 0; c0 < dim4; c0 += LPG) {
+            const int c = c0 + lig;
+            for (int j = 0; j < nrow; j += 8 * RPI) {
+                float4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = j + u * RPI + sub;
+                    const unsigned long long a = ((unsigned long long)(uint32_t)__shfl(hi, r & 63, 64) << 32) | (uint32_t)__shfl(lo, r & 63, 64);
+                    t[u] = (r < nrow && c < dim4) ? reinterpret_cast<const float4 *>(a)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = j + u * RPI + sub;
+                    if (r < nrow && c < dim4) obase[(size_t)r * dim4 + c] = t[u];
+                }
+            }
+        }
     }
 }
 
@@ -98,8 +127,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     if (batch <= 0 || total_l < 0 || total_l > 0x7fffffffL / 4) { set_error("cafe forward: bad size %ld", total_l); return 1; }
     const int total = (int)total_l;
     const int lpg = lanes_per_row(t->dim);
-    const long threads = (long)total * lpg;
-    const int blocks = (int)std::min<long>((threads + 255) / 256, 256 * 16);
+    const int blocks = (int)std::min<long>(((long)total + 255) / 256, 256 * 16);      // a wave per 64 lookups
     FastMod fm1 = make_fastmod(s->n1);
 #define CAFE_FWD(L)                                                                                              \
     hipLaunchKernelGGL(k_forward<L>, dim3(blocks), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold,     \
