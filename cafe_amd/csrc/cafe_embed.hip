@@ -385,11 +385,15 @@ __device__ inline float *row_ptr(uint32_t key, uint32_t item, const int32_t *__r
 // groups or tiles finishes with float atomics.
 __device__ inline int bwd_rank_of(const unsigned long long *key, int n, unsigned long long mine) {
     int r = 0, j = 0;
-    for (; j + 2 <= n; j += 2) {
-        const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(&key[j]);
-        r += (k.x < mine) + (k.y < mine);
+    for (; j + 8 <= n; j += 8) {       // four 16-byte broadcast reads in flight per step
+        const ulonglong2 k0 = *reinterpret_cast<const ulonglong2 *>(&key[j]);
+        const ulonglong2 k1 = *reinterpret_cast<const ulonglong2 *>(&key[j + 2]);
+        const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(&key[j + 4]);
+        const ulonglong2 k3 = *reinterpret_cast<const ulonglong2 *>(&key[j + 6]);
+        r += (k0.x < mine) + (k0.y < mine) + (k1.x < mine) + (k1.y < mine) + (k2.x < mine) + (k2.y < mine) + (k3.x < mine) +
+             (k3.y < mine);
     }
-    if (j < n) r += key[j] < mine;
+    for (; j < n; ++j) r += key[j] < mine;
     return r;
 }
 

@@ -67,7 +67,7 @@ struct EvRes {              // outcome of a move, written by the main owner that
 
 struct Ctl {                // zeroed at the start of every call
     uint32_t changed[kMaxRounds + 2];
-    uint32_t overflow;
+    uint32_t overflow;      // overflow | final_round are read as one 8-byte word by every owner (8-byte aligned)
     uint32_t final_round;
     uint32_t maxpart;       // largest partition (items) of this call
     uint32_t totals[8];     // pops, pushes, clock ticks, threshold crossings, rounds: applied by the closing kernel
@@ -88,6 +88,7 @@ struct Geo {
     FastMod fm1, fm2;
 };
 constexpr size_t kCtlWords = (sizeof(Ctl) + 3) / 4;
+static_assert(offsetof(Ctl, overflow) % 8 == 0 && offsetof(Ctl, final_round) == offsetof(Ctl, overflow) + 4, "stop word");
 
 // What an owner needs to know about one of its items, written once per call by k_scatter into the item's
 // partition region so that owners read one coalesced stream instead of chasing ids[] / scores[] by position.
@@ -252,11 +253,16 @@ __global__ void k_scatter(Geo g, const int32_t *__restrict__ ids, const float *_
 __device__ inline int rank_of(const unsigned long long *key, int total, unsigned long long mine) {
     int r = 0;
     int j = 0;
-    for (; j + 2 <= total; j += 2) {
-        const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(&key[j]);
-        r += (k.x < mine) + (k.y < mine);
+    // eight keys per step, all four 16-byte LDS reads issued before the first compare (the reads are broadcasts)
+    for (; j + 8 <= total; j += 8) {
+        const ulonglong2 k0 = *reinterpret_cast<const ulonglong2 *>(&key[j]);
+        const ulonglong2 k1 = *reinterpret_cast<const ulonglong2 *>(&key[j + 2]);
+        const ulonglong2 k2 = *reinterpret_cast<const ulonglong2 *>(&key[j + 4]);
+        const ulonglong2 k3 = *reinterpret_cast<const ulonglong2 *>(&key[j + 6]);
+        r += (k0.x < mine) + (k0.y < mine) + (k1.x < mine) + (k1.y < mine) + (k2.x < mine) + (k2.y < mine) + (k3.x < mine) +
+             (k3.y < mine);
     }
-    if (j < total) r += key[j] < mine;
+    for (; j < total; ++j) r += key[j] < mine;
     return r;
 }
 
@@ -291,15 +297,16 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
     float *pc = reinterpret_cast<float *>(pay + 4 * CAP);
     uint8_t *po = pay + 8 * CAP;
     __shared__ int heavy[kMaxHeavy];
-    __shared__ __attribute__((aligned(16))) int4 heavy_b[kMaxHeavy][4];      // their table buckets, fetched by phase A
     __shared__ int n_heavy;
 
-    if (ctl->final_round || st->fallback || ctl->overflow) return;
+    // st->fallback is only ever raised by the finish kernels, behind all rounds: owners need not look at it
+    const uint2 stop = *reinterpret_cast<const uint2 *>(&ctl->overflow);
+    const uint32_t o0 = off[blockIdx.x], o1 = off[blockIdx.x + 1];       // requested together with the stop word
+    if (stop.x | stop.y) return;
     const int p = blockIdx.x, tid = threadIdx.x;
     const int prev = (round & 1) ^ 1;
     if (tid == 0) n_heavy = 0;
-    const uint32_t o0 = off[p];
-    const int np = (int)(off[p + 1] - o0);
+    const int np = (int)(o1 - o0);
     const uint32_t ne_raw = round > 1 ? evcnt[prev * g.P1 + p] : 0u;       // moves emitted by LRU round-1
     if (ne_raw > (uint32_t)kCapEv) { if (tid == 0) ctl->overflow = 1; return; }
     const int ne = (int)ne_raw;
@@ -339,6 +346,8 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
     const Rec *recs = rec1 + o0;
     CAFE_STAMP(0, 0);
     CAFE_STAMP_VAL(0, 7, (unsigned long long)total);
+    // the kernel ends when its largest partition is done: let that workgroup's waves issue first on their SIMDs
+    if (total > 2 * kRankSortMax) __builtin_amdgcn_s_setprio(3);
 
     // key layout: [bucket in partition : 25][2*position + phase : 23][16 bits: item -> index of its record, move -> index | kind<<15]
     if (total <= kRankSortMax) {
@@ -403,23 +412,31 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
     int changed = 0;
     // Phase A: one lane per bucket replays the bucket's items in batch order.  Buckets with many items (a
     // heavy id) are left to phase B, where a whole wave works on one bucket.
-    for (int s = tid; s < total; s += kThreads) {
+    // The table bucket of the next head is requested before the current one is replayed, so that a lane with several
+    // heads does not pay a memory round trip (and the completion of its own staging stores) per head.
+    auto classify = [&](int s) -> int {        // 0: not a head, 1: replay here, 2: handed to phase B
+        if (s >= total) return 0;
         const uint32_t bl = (uint32_t)(key[s] >> 39);
-        if (s != 0 && (uint32_t)(key[s - 1] >> 39) == bl) continue;
+        if (s != 0 && (uint32_t)(key[s - 1] >> 39) == bl) return 0;
         if (s + kHeavySeg <= total && (uint32_t)(key[s + kHeavySeg - 1] >> 39) == bl) {
-            int at = atomicAdd(&n_heavy, 1);
-            if (at < kMaxHeavy) {
-                const int4 *src = reinterpret_cast<const int4 *>(&mt[b0 + (int)bl]);
-                heavy[at] = s;
-                heavy_b[at][0] = src[0]; heavy_b[at][1] = src[1]; heavy_b[at][2] = src[2]; heavy_b[at][3] = src[3];
-                continue;
-            }
+            const int at = atomicAdd(&n_heavy, 1);
+            if (at < kMaxHeavy) { heavy[at] = s; return 2; }
         }
-        MainR b;
-        load_main(b, &mt[b0 + (int)bl]);
+        return 1;
+    };
+    MainR nb;
+    int nmode = classify(tid);
+    if (nmode == 1) load_main(nb, &mt[b0 + (int)(uint32_t)(key[tid] >> 39)]);
+    for (int s = tid; s < total; s += kThreads) {
+        const int mode = nmode;
+        MainR b = nb;
+        nmode = classify(s + kThreads);
+        if (nmode == 1) load_main(nb, &mt[b0 + (int)(uint32_t)(key[s + kThreads] >> 39)]);
+        if (mode != 1) continue;
+        const uint32_t bl = (uint32_t)(key[s] >> 39);
         sync_flip(b, gflip);
 #ifdef CAFE_PROF
-        if (s == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CAFE_STAMP(0, 5); }
+        if (s == 0) { CAFE_STAMP(0, 5); }
 #endif
         for (int e = s; e < total && (uint32_t)(key[e] >> 39) == bl; ++e) {
             const unsigned long long k = key[e];
@@ -454,11 +471,13 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
     {
         const int lane = tid & 63, wave = tid >> 6;
         const int nh = min(n_heavy, kMaxHeavy);
+        MainR nhb;
+        if (wave < nh) load_main(nhb, &mt[b0 + (int)(uint32_t)(key[heavy[wave]] >> 39)]);
         for (int h = wave; h < nh; h += kThreads / 64) {
             const int s = heavy[h];
             const uint32_t bl = (uint32_t)(key[s] >> 39);
-            MainR b;
-            load_main(b, reinterpret_cast<const MainBucket *>(&heavy_b[h][0]));
+            MainR b = nhb;
+            if (h + kThreads / 64 < nh) load_main(nhb, &mt[b0 + (int)(uint32_t)(key[heavy[h + kThreads / 64]] >> 39)]);
             sync_flip(b, gflip);
             int e = s;
             while (e < total && (uint32_t)(key[e] >> 39) == bl) {
@@ -617,17 +636,26 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
     uint8_t *po = pay + 8 * CAP;
     __shared__ int n_miss, n_ev;
 
-    if (ctl->final_round || st->fallback || ctl->overflow) return;
+#ifdef CAFE_PROF
+    CAFE_STAMP(1, 4);
+    const unsigned long long mt0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const uint2 stop = *reinterpret_cast<const uint2 *>(&ctl->overflow);
+    const uint32_t round_changed = ctl->changed[round];
+    const uint32_t o0 = off[g.P1 + 1 + blockIdx.x], o1 = off[g.P1 + 2 + blockIdx.x];
+    if (stop.x | stop.y) return;
     const int q = blockIdx.x, tid = threadIdx.x;
     const int par = round & 1, nxt = par ^ 1;
-    if (!ctl->changed[round]) {                    // the miss set repeated: the previous round is the answer
+#ifdef CAFE_PROF
+    CAFE_STAMP(1, 5);
+#endif
+    if (!round_changed) {                          // the miss set repeated: the previous round is the answer
         if (!BIG && q == 0 && tid == 0) ctl->final_round = (uint32_t)round;
         return;
     }
     if (!BIG) for (int p = q; p < g.P1; p += gridDim.x) if (tid == 0) evcnt[nxt * g.P1 + p] = 0;
 
-    const uint32_t o0 = off[g.P1 + 1 + q];
-    const int cnt = (int)(off[g.P1 + 1 + q + 1] - o0);
+    const int cnt = (int)(o1 - o0);
     if (BIG ? (cnt <= kCapSmall) : (cnt > kCapSmall)) return;
     if (cnt > CAP) { if (tid == 0) ctl->overflow = 1; return; }
     MoveEv *mine_ev = myev + (size_t)q * kCapEvL;
@@ -656,22 +684,45 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
         uint32_t x = 0; float c = 0.f;
         if (tid < cnt) {
             const Rec r = recs[tid];
+#ifdef CAFE_PROF
+            if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CAFE_STAMP(1, 6); }
+#endif
             if (miss[r.pos]) {
                 k = ((unsigned long long)r.bl << 40) | ((unsigned long long)r.pos << 16);
                 x = r.x; c = r.c;
             }
         }
+#ifdef CAFE_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
         const unsigned long long mm = __ballot(k != ~0ull);
         if ((tid & 63) == 0 && mm) atomicAdd(&n_miss, __popcll(mm));
         if (tid < ((cnt + 1) & ~1)) key[tid] = k;
+#ifdef CAFE_PROF
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+#ifdef CAFE_PROF
+        const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+#endif
         total = n_miss;
         if (tid == 0) { stage_tot[g.P1 + q] = (uint32_t)total; if (total == 0) mycnt[q] = 0; }
         if (total == 0) return;
         const int r = k != ~0ull ? rank_of(key, cnt, k) : 0;
+#ifdef CAFE_PROF
+        const unsigned long long c3 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
         if (k != ~0ull) { key[r] = k; px[r] = x; pc[r] = c; }
         __syncthreads();
+#ifdef CAFE_PROF
+        const unsigned long long c4 = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && round == CAFE_PROF_ROUND) {
+            unsigned long long *d = &g_dbg[1][blockIdx.x * 8];
+            d[4] = ((c1 - c0) << 32) | (c2 - c1);  d[5] = ((c3 - c2) << 32) | (c4 - c3);
+        }
+#endif
     } else {
         int mine = 0;
         for (int j = tid; j < cnt; j += kThreads) {
@@ -750,6 +801,12 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
     }
     if (over) ctl->overflow = 1;
     CAFE_STAMP(1, 3);
+#ifdef CAFE_PROF
+    if (threadIdx.x == 0 && round == CAFE_PROF_ROUND) {
+        const unsigned long long mt1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+        (void)mt1; (void)rt1;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -39,10 +39,18 @@ for t, (name, phases) in enumerate([("main", ["load+sort", "phaseA", "phaseB", "
         print(f"A: replay of first bucket (wave 0) p50 {np.median(d):.2f} mean {d.mean():.2f}")
         d = (b[:, 2] - b[:, 6]) / 100.0
         print(f"A: first bucket done -> barrier passed p50 {np.median(d):.2f} mean {d.mean():.2f}")
+    if t == 1:
+        for nm, v in [("miss-loaded -> before barrier1", b[:, 4] >> 32), ("barrier1", b[:, 4] & 0xffffffff), ("rank_of", b[:, 5] >> 32), ("barrier2 + writes + barrier3", b[:, 5] & 0xffffffff)]:
+            print(f"L cycles: {nm}: p50 {np.median(v):.0f} mean {v.mean():.0f} p99 {np.percentile(v, 99):.0f}")
+    if False:
+        for nm, x, y in [("entry->flags read", 4, 5), ("flags->first barrier (off, ldirty)", 5, 0), ("barrier->rec loaded", 0, 6), ("rec loaded->sorted (miss gather, rank)", 6, 1)]:
+            dd = (b[:, y] - b[:, x]) / 100.0
+            print(f"L: {nm}: p50 {np.median(dd):.2f} mean {dd.mean():.2f} p99 {np.percentile(dd, 99):.2f}")
     d = (b[:, n] - b[:, 0]) / 100.0
     print(f"block total mean {d.mean():.2f} p50 {np.median(d):.2f} max {d.max():.2f}; first start->last start {(b[:, 0].max() - t0) / 100.0:.2f}; last end {(b[:, n].max() - t0) / 100.0:.2f}")
     for o in np.argsort(-d)[:5]:
-        print("  slow: items", tot[o], "heavy", nh[o], "total", d[o], "phases", [float((b[o, k + 1] - b[o, k]) / 100.0) for k in range(n)], "start", (b[o, 0] - t0) / 100.0)
+        print("  slow: items", tot[o], "heavy", nh[o], "total", d[o], "phases", [float((b[o, k + 1] - b[o, k]) / 100.0) for k in range(n)], "start", (b[o, 0] - t0) / 100.0,
+              ("A parts", float((b[o, 5] - b[o, 1]) / 100.0), float((b[o, 6] - b[o, 5]) / 100.0), float((b[o, 2] - b[o, 6]) / 100.0)) if t == 0 else "")
     st = (b[:, 0] - t0) / 100.0
     for lo, hi in [(0, 1), (1, 10), (10, 20), (20, 30), (30, 40), (40, 60)]:
         sel = (st >= lo) & (st < hi)
