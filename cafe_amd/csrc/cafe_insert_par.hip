@@ -34,7 +34,8 @@
 namespace cafe {
 
 constexpr int kThreads = 256;
-constexpr int kCapSmall = 2048;   // items an owner of a normal partition sorts in LDS (several workgroups per CU)
+constexpr int kCapSmall = 1024;   // items an owner of a normal partition sorts in LDS (several workgroups per CU)
+constexpr int kCapHot = 2048;    // ... of a hot-bypass partition (they hold the heavy ids)
 constexpr int kCapBig = 8192;     // ... of a partition that holds a heavy id (one workgroup per CU)
 constexpr int kCapEv = 256;       // moves one main partition can receive per round
 constexpr int kCapEvL = 256;      // moves one LRU partition can emit per round
@@ -69,13 +70,15 @@ struct Ctl {                // zeroed at the start of every call
     uint32_t changed[kMaxRounds + 2];
     uint32_t overflow;      // overflow | final_round are read as one 8-byte word by every owner (8-byte aligned)
     uint32_t final_round;
-    uint32_t maxpart;       // largest partition (items) of this call
+    uint32_t maxpart;       // largest owner partition (items) of this call
+    uint32_t maxhot;        // largest hot-bypass partition
     uint32_t totals[8];     // pops, pushes, clock ticks, threshold crossings, rounds: applied by the closing kernel
 };
 
 struct ParWorkspace {
-    DevBuf zr;              // [Ctl][cnt: P1+P2][evcnt: 2*P1], zeroed by the per-call prologue kernel
+    DevBuf zr;              // [Ctl][cnt: P1+P2][evcnt: 2*P1][hot cnt: P1], zeroed by the per-call prologue kernel
     DevBuf off, rank, items, ev, evres, miss, outm, outl, stage_m, stage_l, stage_tot, prevcnt;
+    DevBuf hkey, hrun, hfin;
     DevBuf ldirty, myev, mycnt;
     DevBuf flags, blocksum, ranks;
     void *evres_seen = nullptr;
@@ -85,6 +88,8 @@ struct ParWorkspace {
 struct Geo {
     int n, n1, n2, P1, P2, bpp1, bpp2;
     int end_bit1, end_bit2;     // one past the highest key bit the owners' sorts have to look at
+    int hot;                    // 1: ids that sit hot in the main table before the batch bypass the owner rounds
+    uint32_t gflip;             // flip bit of this call (known on the host)
     FastMod fm1, fm2;
 };
 constexpr size_t kCtlWords = (sizeof(Ctl) + 3) / 4;
@@ -148,21 +153,22 @@ constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
 // bytes of the LDS region an owner shares between the sort's scratch and its per-item payload arrays (x, score, flags)
 template <int CAP>
 constexpr size_t pay_bytes() {
-    return (cmax(cmax(cmax(sort_bytes<2>(), sort_bytes<4>()), cmax(sort_bytes<8>(), sort_bytes<(CAP > 2048 ? CAP / kThreads : 8)>())),
-                 (size_t)9 * CAP) + 15) & ~(size_t)15;
+    size_t b = cmax(sort_bytes<2>(), (size_t)9 * CAP);
+    if (CAP > 2 * kThreads) b = cmax(b, sort_bytes<4>());
+    if (CAP > 4 * kThreads) b = cmax(b, sort_bytes<8>());
+    if (CAP > 8 * kThreads) b = cmax(b, sort_bytes<(CAP > 8 * kThreads ? CAP / kThreads : 8)>());
+    return (b + 15) & ~(size_t)15;
 }
 template <int CAP>
 __device__ inline void block_sort(unsigned long long *key, int total, int begin_bit, int end_bit, void *storage) {
-    if (total <= 2 * kThreads) block_sort_ipt<2>(key, total, begin_bit, end_bit, storage);
-    else if (total <= 4 * kThreads) block_sort_ipt<4>(key, total, begin_bit, end_bit, storage);
-    else if (CAP <= 8 * kThreads || total <= 8 * kThreads) block_sort_ipt<8>(key, total, begin_bit, end_bit, storage);
-    else block_sort_ipt<(CAP > 8 * kThreads ? CAP / kThreads : 8)>(key, total, begin_bit, end_bit, storage);
-}
-
-__device__ inline int next_pow2(int v) {
-    int p = 64;
-    while (p < v) p <<= 1;
-    return p;
+    if constexpr (CAP <= 2 * kThreads) {
+        block_sort_ipt<2>(key, total, begin_bit, end_bit, storage);
+    } else {
+        if (total <= 2 * kThreads) block_sort_ipt<2>(key, total, begin_bit, end_bit, storage);
+        else if (total <= 4 * kThreads) block_sort_ipt<4>(key, total, begin_bit, end_bit, storage);
+        else if (CAP <= 8 * kThreads || total <= 8 * kThreads) block_sort_ipt<8>(key, total, begin_bit, end_bit, storage);
+        else block_sort_ipt<(CAP > 8 * kThreads ? CAP / kThreads : 8)>(key, total, begin_bit, end_bit, storage);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -170,39 +176,77 @@ __device__ inline int next_pow2(int v) {
 // Ranks inside a partition come from LDS atomics per 8192-item chunk plus one global atomic per
 // (chunk, non-empty partition); the order inside a partition is arbitrary, owners sort by position.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_assign(Geo g, const int32_t *__restrict__ ids, uint32_t *__restrict__ cnt /* [P1+P2] */,
+// An id that sits in the main table with a hot slot before the batch ("hot" here) is a guaranteed main-table hit for
+// the whole batch: hot slots are never replaced (sketch.cpp:253-258), it never pops and never reaches the LRU table.
+// Its only effects are the ordered sum of its scores and threshold-crossing counts, so such items bypass the owner
+// rounds (k_hot_chain).  A bucket whose lazy decay is pending is left to the owners as a whole.
+__device__ inline int hot_slot(const MainBucket *__restrict__ mt, int h1, uint32_t x, uint32_t gflip) {
+    const int4 *p = reinterpret_cast<const int4 *>(&mt[h1]);
+    const int4 v = p[0], d = p[1];
+    const uint32_t flip = mt[h1].flip;
+    int hit = -1;
+    if ((uint32_t)v.w == x && d.w) hit = 3;
+    if ((uint32_t)v.z == x && d.z) hit = 2;
+    if ((uint32_t)v.y == x && d.y) hit = 1;
+    if ((uint32_t)v.x == x && d.x) hit = 0;
+    // the reference stops at the first slot holding the id (sketch.cpp:214-215): a hot copy behind a cold one is not hit
+    int first = -1;
+    if ((uint32_t)v.w == x) first = 3;
+    if ((uint32_t)v.z == x) first = 2;
+    if ((uint32_t)v.y == x) first = 1;
+    if ((uint32_t)v.x == x) first = 0;
+    return (flip == gflip && hit >= 0 && hit == first) ? hit : -1;
+}
+constexpr uint32_t kHotBit = 0x80000000u;       // rank1[i]: bit 31 hot, bits 29-30 slot, low bits rank
+
+__global__ void __launch_bounds__(1024) k_assign(Geo g, const MainBucket *__restrict__ mt, const int32_t *__restrict__ ids,
+                                                 uint32_t *__restrict__ cnt /* [P1+P2] */, uint32_t *__restrict__ cnth /* [P1] */,
                                                  uint32_t *__restrict__ rank1, uint32_t *__restrict__ rank2) {
-    extern __shared__ uint32_t hist[];          // [P1 + P2]
-    uint32_t *h1 = hist, *h2 = hist + g.P1;
-    for (int b = threadIdx.x; b < g.P1 + g.P2; b += blockDim.x) hist[b] = 0;
+    extern __shared__ uint32_t hist[];          // [P1 + P2 + P1]
+    uint32_t *h1 = hist, *h2 = hist + g.P1, *hh = hist + g.P1 + g.P2;
+    const int nb = g.P1 + g.P2 + (g.hot ? g.P1 : 0);
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     const int begin = blockIdx.x * kAssignChunk, end = min(begin + kAssignChunk, g.n);
     for (int i = begin + threadIdx.x; i < end; i += blockDim.x) {
-        uint32_t x = (uint32_t)ids[i];
-        rank1[i] = atomicAdd(&h1[fast_hash(x, g.fm1) / g.bpp1], 1u);
-        rank2[i] = atomicAdd(&h2[fast_hash(x, g.fm2) / g.bpp2], 1u);
+        const uint32_t x = (uint32_t)ids[i];
+        const int b1 = fast_hash(x, g.fm1);
+        const int slot = g.hot ? hot_slot(mt, b1, x, g.gflip) : -1;
+        if (slot >= 0) {
+            rank1[i] = atomicAdd(&hh[b1 / g.bpp1], 1u) | kHotBit | ((uint32_t)slot << 29);
+        } else {
+            rank1[i] = atomicAdd(&h1[b1 / g.bpp1], 1u);
+            rank2[i] = atomicAdd(&h2[fast_hash(x, g.fm2) / g.bpp2], 1u);
+        }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < g.P1 + g.P2; b += blockDim.x) {
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
         uint32_t c = hist[b];
-        if (c) hist[b] = atomicAdd(&cnt[b], c);
+        if (c) hist[b] = atomicAdd(b < g.P1 + g.P2 ? &cnt[b] : &cnth[b - g.P1 - g.P2], c);
     }
     __syncthreads();
     for (int i = begin + threadIdx.x; i < end; i += blockDim.x) {
-        uint32_t x = (uint32_t)ids[i];
-        rank1[i] += h1[fast_hash(x, g.fm1) / g.bpp1];
-        rank2[i] += h2[fast_hash(x, g.fm2) / g.bpp2];
+        const uint32_t x = (uint32_t)ids[i];
+        const int p1 = fast_hash(x, g.fm1) / g.bpp1;
+        const uint32_t r1 = rank1[i];
+        if (r1 & kHotBit) {
+            rank1[i] = r1 + hh[p1];
+        } else {
+            rank1[i] = r1 + h1[p1];
+            rank2[i] += h2[fast_hash(x, g.fm2) / g.bpp2];
+        }
     }
 }
 
 // block 0: offsets of the main partitions, block 1: of the LRU partitions
-__global__ void __launch_bounds__(1024) k_offsets(Geo g, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off,
-                                                  Ctl *ctl, const DevState *st) {
+__global__ void __launch_bounds__(1024) k_offsets(Geo g, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ cnth,
+                                                  uint32_t *__restrict__ off, Ctl *ctl, const DevState *st) {
     __shared__ uint32_t sh[1024];
     __shared__ uint32_t carry;
-    const int P = blockIdx.x == 0 ? g.P1 : g.P2;
-    const uint32_t *c = blockIdx.x == 0 ? cnt : cnt + g.P1;
-    uint32_t *o = blockIdx.x == 0 ? off : off + g.P1 + 1;
+    // block 0: main partitions, 1: LRU partitions, 2: hot-bypass partitions (offsets behind the other two)
+    const int P = blockIdx.x == 1 ? g.P2 : g.P1;
+    const uint32_t *c = blockIdx.x == 0 ? cnt : blockIdx.x == 1 ? cnt + g.P1 : cnth;
+    uint32_t *o = blockIdx.x == 0 ? off : blockIdx.x == 1 ? off + g.P1 + 1 : off + g.P1 + g.P2 + 2;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     uint32_t over = 0, vmax = 0;
@@ -226,24 +270,33 @@ __global__ void __launch_bounds__(1024) k_offsets(Geo g, const uint32_t *__restr
     }
     if (threadIdx.x == 0) o[P] = carry;
     if (over) ctl->overflow = 1;
-    if (vmax) atomicMax(&ctl->maxpart, vmax);
+    if (vmax) atomicMax(blockIdx.x == 2 ? &ctl->maxhot : &ctl->maxpart, vmax);
     // the LRU clock placeholder clock0 + 1 + position must stay a positive int
     if (threadIdx.x == 0 && (long long)st->clk + g.n + 2 >= 0x7fffffffLL) ctl->overflow = 1;
 }
 
 __global__ void k_scatter(Geo g, const int32_t *__restrict__ ids, const float *__restrict__ scores,
                           const uint32_t *__restrict__ off, const uint32_t *__restrict__ rank1,
-                          const uint32_t *__restrict__ rank2, Rec *__restrict__ rec1, Rec *__restrict__ rec2) {
+                          const uint32_t *__restrict__ rank2, Rec *__restrict__ rec1, Rec *__restrict__ rec2,
+                          Rec *__restrict__ rech) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.n) return;
     const uint32_t x = (uint32_t)ids[i];
     const float c = scores ? scores[i] : 1.0f;
-    const int h1 = fast_hash(x, g.fm1), h2 = fast_hash(x, g.fm2);
-    const int p1 = h1 / g.bpp1, p2 = h2 / g.bpp2;
+    const int h1 = fast_hash(x, g.fm1);
+    const int p1 = h1 / g.bpp1;
+    const uint32_t r1 = rank1[i];
     Rec r;
     r.pos = (uint32_t)i; r.x = x; r.c = c;
     r.bl = (uint32_t)(h1 - p1 * g.bpp1);
-    rec1[off[p1] + rank1[i]] = r;
+    if (r1 & kHotBit) {
+        r.bl = (r.bl << 2) | ((r1 >> 29) & 3u);            // bucket in partition, slot
+        rech[off[g.P1 + g.P2 + 2 + p1] + (r1 & 0x1fffffffu)] = r;
+        return;
+    }
+    rec1[off[p1] + r1] = r;
+    const int h2 = fast_hash(x, g.fm2);
+    const int p2 = h2 / g.bpp2;
     r.bl = (uint32_t)(h2 - p2 * g.bpp2);
     rec2[off[g.P1 + 1 + p2] + rank2[i]] = r;
 }
@@ -264,6 +317,144 @@ __device__ inline int rank_of(const unsigned long long *key, int total, unsigned
     }
     for (; j < total; ++j) r += key[j] < mine;
     return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hot bypass: ordered score sums of the ids that are hot before the batch (see hot_slot above)
+// ------------------------------------------------------------------------------------------------
+// key layout: [bucket in partition << 2 | slot : 25][2 * position : 23][index of the record : 16]
+// Outputs, all indexed like the partition's records (sorted order): hkey (sort keys), hrun (score of the slot after
+// the item: what a move into the bucket later in the batch has to see, sketch.cpp:244-247), and at the first item
+// of every slot hfin = {bucket * 4 + slot, final score} (-1 elsewhere), applied to the table by k_commit.
+template <int CAP, bool BIG>
+__global__ void __launch_bounds__(kThreads) k_hot_chain(Geo g, const MainBucket *__restrict__ mt, const DevState *__restrict__ st,
+                                                        Ctl *ctl, const uint32_t *__restrict__ off, const Rec *__restrict__ rech,
+                                                        unsigned long long *__restrict__ hkey, float *__restrict__ hrun,
+                                                        int2 *__restrict__ hfin, uint8_t *__restrict__ miss,
+                                                        uint8_t *__restrict__ outm) {
+    __shared__ __attribute__((aligned(16))) unsigned long long key[CAP];
+    __shared__ __attribute__((aligned(16))) unsigned char pay[pay_bytes<CAP>()];
+    float *pc = reinterpret_cast<float *>(pay);              // score, then running score
+    uint8_t *po = pay + 4 * CAP;
+    __shared__ int heavy[kMaxHeavy];
+    __shared__ int n_heavy;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const uint32_t o0 = off[g.P1 + g.P2 + 2 + p], o1 = off[g.P1 + g.P2 + 3 + p];
+    if (ctl->overflow) return;
+    const int total = (int)(o1 - o0);
+    if (BIG ? (total <= kCapHot) : (total > kCapHot)) return;
+    if (total > CAP) { if (tid == 0) ctl->overflow = 1; return; }
+    if (total == 0) return;
+    if (tid == 0) n_heavy = 0;
+    const int b0 = p * g.bpp1;
+    const Rec *recs = rech + o0;
+    if (total > 2 * kRankSortMax) __builtin_amdgcn_s_setprio(3);
+    if (total <= kRankSortMax) {
+        unsigned long long k = ~0ull;
+        float c = 0.f;
+        if (tid < total) {
+            const Rec r = recs[tid];
+            k = ((unsigned long long)r.bl << 39) | ((unsigned long long)(2u * r.pos) << 16);
+            c = r.c;
+        }
+        if (tid < ((total + 1) & ~1)) key[tid] = k;
+        __syncthreads();
+        const int r = tid < total ? rank_of(key, total, k) : 0;
+        __syncthreads();
+        if (tid < total) { key[r] = k; pc[r] = c; }
+        __syncthreads();
+    } else {
+        for (int j = tid; j < total; j += kThreads) {
+            const Rec r = recs[j];
+            key[j] = ((unsigned long long)r.bl << 39) | ((unsigned long long)(2u * r.pos) << 16) | (unsigned)j;
+        }
+        __syncthreads();
+        block_sort<CAP>(key, total, 16, g.end_bit1 + 2, pay);
+        for (int s = tid; s < total; s += kThreads) pc[s] = recs[(int)(key[s] & 0xffffu)].c;
+        __syncthreads();
+    }
+    const float thr = st->thr;
+    int2 *fin = hfin + o0;
+    // short runs: one lane each; long runs: a wave each, 64 items at a time
+    for (int s = tid; s < total; s += kThreads) {
+        const uint32_t bs = (uint32_t)(key[s] >> 39);
+        const bool head = s == 0 || (uint32_t)(key[s - 1] >> 39) != bs;
+        if (!head) { fin[s] = make_int2(-1, 0); continue; }
+        if (s + kHeavySeg <= total && (uint32_t)(key[s + kHeavySeg - 1] >> 39) == bs) {
+            const int at = atomicAdd(&n_heavy, 1);
+            if (at < kMaxHeavy) { heavy[at] = s; continue; }
+        }
+        const int bucket = b0 + (int)(bs >> 2), slot = (int)(bs & 3u);
+        float acc = mt[bucket].cnt[slot];
+        for (int e = s; e < total && (uint32_t)(key[e] >> 39) == bs; ++e) {
+            const float c = pc[e];
+            acc += c;
+            po[e] = (acc >= thr && acc - c < thr) ? oCross : 0;         // sketch.cpp:218-220
+            pc[e] = acc;
+        }
+        fin[s] = make_int2(bucket * 4 + slot, __float_as_int(acc));
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int nh = min(n_heavy, kMaxHeavy);
+        for (int h = wave; h < nh; h += kThreads / 64) {
+            const int s = heavy[h];
+            const uint32_t bs = (uint32_t)(key[s] >> 39);
+            const int bucket = b0 + (int)(bs >> 2), slot = (int)(bs & 3u);
+            float acc = mt[bucket].cnt[slot];
+            for (int e = s;; e += 64) {
+                const int idx = e + lane;
+                const bool act = idx < total && (uint32_t)(key[idx] >> 39) == bs;
+                const unsigned long long m = __ballot(act);
+                if (!m) break;
+                const int r = __popcll(m);                    // the run's items are contiguous from lane 0
+                const float c = act ? pc[idx] : 0.0f;
+                float mine = 0.0f;
+                for (int j = 0; j < r; ++j) {
+                    acc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), j));
+                    mine = lane == j ? acc : mine;
+                }
+                if (act) {
+                    po[idx] = (mine >= thr && mine - c < thr) ? oCross : 0;
+                    pc[idx] = mine;
+                }
+                if (r < 64) break;
+            }
+            if (lane == 0) fin[s] = make_int2(bucket * 4 + slot, __float_as_int(acc));
+        }
+    }
+    __syncthreads();
+    for (int s = tid; s < total; s += kThreads) {
+        const unsigned long long k = key[s];
+        const uint32_t pos = ((uint32_t)(k >> 16) & 0x7fffffu) >> 1;
+        hkey[o0 + s] = k;
+        hrun[o0 + s] = pc[s];
+        outm[pos] = po[s];
+        miss[pos] = 0;
+    }
+}
+
+// Score of hot slot `slot` of bucket `bl` (partition-local) as a move at `time` sees it: the running score behind the
+// slot's last bypassed item before `time`, or `base` (the table's value) if there is none.
+__device__ inline float hot_cnt_at(const unsigned long long *__restrict__ hk, const float *__restrict__ hr, int nh,
+                                   uint32_t bl, int slot, uint32_t time, float base) {
+    const unsigned long long target = ((unsigned long long)((bl << 2) | (uint32_t)slot) << 23) | time;   // in units of key >> 16
+    int lo = 0, hi = nh;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((hk[mid] >> 16) < target) lo = mid + 1; else hi = mid;
+    }
+    if (lo > 0 && (uint32_t)(hk[lo - 1] >> 39) == ((bl << 2) | (uint32_t)slot)) return hr[lo - 1];
+    return base;
+}
+__device__ inline void patch_hot(MainR &b, const unsigned long long *__restrict__ hk, const float *__restrict__ hr, int nh,
+                                 uint32_t bl, uint32_t time) {
+    if (nh <= 0) return;
+    if (b.d0) b.c0 = hot_cnt_at(hk, hr, nh, bl, 0, time, b.c0);
+    if (b.d1) b.c1 = hot_cnt_at(hk, hr, nh, bl, 1, time, b.c1);
+    if (b.d2) b.c2 = hot_cnt_at(hk, hr, nh, bl, 2, time, b.c2);
+    if (b.d3) b.c3 = hot_cnt_at(hk, hr, nh, bl, 3, time, b.c3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -290,7 +481,7 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
     Ctl *ctl, const uint32_t *__restrict__ off, const Rec *__restrict__ rec1, const uint32_t *__restrict__ evcnt /* [2][P1] */,
     const MoveEv *__restrict__ ev, EvRes *__restrict__ evres, uint8_t *__restrict__ miss, uint8_t *__restrict__ outm,
     MainBucket *__restrict__ stage_m, uint32_t *__restrict__ stage_tot, uint32_t *__restrict__ prevcnt,
-    uint8_t *__restrict__ ldirty /* [2][P2] */) {
+    uint8_t *__restrict__ ldirty /* [2][P2] */, const unsigned long long *__restrict__ hkey, const float *__restrict__ hrun) {
     __shared__ __attribute__((aligned(16))) unsigned long long key[CAP];
     __shared__ __attribute__((aligned(16))) unsigned char pay[pay_bytes<CAP>()];     // sort scratch, then x | score | flags
     uint32_t *px = reinterpret_cast<uint32_t *>(pay);
@@ -344,6 +535,9 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
     const int b0 = p * g.bpp1;
     const int par = round & 1;
     const Rec *recs = rec1 + o0;
+    // this partition's bypassed hot items, looked at only when a move arrives (it compares all four scores)
+    const uint32_t oh0 = g.hot && ne ? off[g.P1 + g.P2 + 2 + p] : 0u;
+    const int nhot = g.hot && ne ? (int)(off[g.P1 + g.P2 + 3 + p] - oh0) : 0;
     CAFE_STAMP(0, 0);
     CAFE_STAMP_VAL(0, 7, (unsigned long long)total);
     // the kernel ends when its largest partition is done: let that workgroup's waves issue first on their SIMDs
@@ -450,6 +644,7 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
             } else {
                 ctx.pushed = 0;
                 const int32_t dic = ev[evbase + (int)(k & 0x7fffu)].dic;
+                patch_hot(b, hkey + oh0, hrun + oh0, nhot, bl, time);
                 int ok = main_move(b, px[e], pc[e], dic, ctx);
                 EvRes r;
                 r.tag = call_tag; r.kind = ((k >> 15) & 1u) ? 1 : 2; r.ok = ok; r.pushed = ctx.pushed; r.pad = 0;
@@ -573,6 +768,7 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
                 } else {
                     ctx.pushed = 0;
                     const int32_t dic = ev[evbase + (int)(k0 & 0x7fffu)].dic;
+                    patch_hot(b, hkey + oh0, hrun + oh0, nhot, bl, time0);
                     int ok = main_move(b, x0, pc[e], dic, ctx);
                     if (lane == 0) {
                         EvRes r;
@@ -900,6 +1096,7 @@ __global__ void __launch_bounds__(kScanBlock) k_finish_ranks(Geo g, int nblocks,
             ctl->totals[3] = (uint32_t)tot[3]; ctl->totals[4] = ctl->final_round;
             st->rounds = (int32_t)ctl->final_round;
             st->maxpart = (int32_t)ctl->maxpart;
+            st->pad[3] = (int32_t)ctl->maxhot;
             if (!ok) st->fallback = 1;
         }
         tot[0] = tot[1] = tot[2] = 0;                 // block 0 starts at rank 0
@@ -928,7 +1125,8 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, MainBucket *mt, LruBucket
                                                 const uint32_t *__restrict__ stage_tot, const MainBucket *__restrict__ stage_m,
                                                 const LruBucket *__restrict__ stage_l, const uint8_t *__restrict__ flags,
                                                 const int32_t *__restrict__ pushval, const uint32_t *__restrict__ poprank,
-                                                const uint32_t *__restrict__ pushrank, const uint32_t *__restrict__ clkrank) {
+                                                const uint32_t *__restrict__ pushrank, const uint32_t *__restrict__ clkrank,
+                                                const int2 *__restrict__ hfin) {
     if (st->fallback) return;
     const uint32_t head = st->fifo_head, len0 = st->fifo_len;
     const int32_t clk0 = st->clk;
@@ -947,6 +1145,20 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, MainBucket *mt, LruBucket
                 int4 *o = reinterpret_cast<int4 *>(&mt[m.y]);
                 o[0] = v; o[1] = d; o[2] = c;
                 mt[m.y].flip = (uint32_t)m.x;
+            }
+            if (g.hot) {
+                // final scores of the bypassed hot slots of this partition, behind its staged buckets (which carry
+                // the pre-batch score in those slots)
+                const uint32_t oh0 = off[g.P1 + g.P2 + 2 + part];
+                const int nh = (int)(off[g.P1 + g.P2 + 3 + part] - oh0);
+                // both writers are waves of this workgroup (one CU, one L2): once the staged stores are acknowledged,
+                // later stores to the same words land behind them
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                for (int s = threadIdx.x; s < nh; s += blockDim.x) {
+                    const int2 f = hfin[oh0 + s];
+                    if (f.x >= 0) mt[f.x >> 2].cnt[f.x & 3] = __int_as_float(f.y);
+                }
             }
         } else {
             const LruBucket *stage = stage_l + off[g.P1 + 1 + (part - g.P1)];
@@ -1000,8 +1212,10 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     g.end_bit2 = 40 + bits(g.bpp2);
     const size_t N = (size_t)n, PP = (size_t)g.P1 + g.P2;
     const int nblocks = (n + kScanBlock - 1) / kScanBlock;
-    if (w.zr.reserve(4 * (kCtlWords + PP + 2 * (size_t)g.P1) + 16) || w.off.reserve(4 * PP + 16) || w.rank.reserve(8 * N) ||
-        w.items.reserve(2 * sizeof(Rec) * N) || w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * kCapEv) ||
+    g.hot = s->opt_hot_bypass ? 1 : 0;
+    g.gflip = (uint32_t)s->flip;
+    if (w.zr.reserve(4 * (kCtlWords + PP + 3 * (size_t)g.P1) + 16) || w.off.reserve(4 * (PP + g.P1) + 32) || w.rank.reserve(8 * N) ||
+        w.items.reserve(3 * sizeof(Rec) * N) || w.hkey.reserve(8 * N + 16) || w.hrun.reserve(4 * N + 16) || w.hfin.reserve(8 * N + 16) || w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * kCapEv) ||
         w.evres.reserve(sizeof(EvRes) * N) || w.miss.reserve(N) || w.outm.reserve(N) || w.outl.reserve(N) ||
         w.stage_m.reserve(sizeof(MainBucket) * (N + (size_t)g.P1 * kCapEv)) || w.stage_l.reserve(sizeof(LruBucket) * N) ||
         w.stage_tot.reserve(4 * PP + 4) || w.prevcnt.reserve(4 * (size_t)g.P1 + 4) || w.ldirty.reserve(2 * (size_t)g.P2 + 4) ||
@@ -1021,18 +1235,19 @@ int par_prepare(cafe_sketch *s, int n, uint32_t **zero, int *zero_words) {
     Geo g;
     if (ensure_ws(s, n, g)) return 1;
     *zero = s->par->zr.as<uint32_t>();
-    *zero_words = (int)(kCtlWords + (size_t)g.P1 + g.P2 + 2 * (size_t)g.P1);
+    *zero_words = (int)(kCtlWords + (size_t)g.P1 + g.P2 + 3 * (size_t)g.P1);
     return 0;
 }
 
 // How many rounds to enqueue and whether to enqueue the big-partition variants are guesses from what recent calls
 // needed (a pinned copy of the device state trails every insert).  A wrong guess is never a wrong result: a batch
 // that is not settled, or meets a partition without an owner kernel, is handed to the in-order kernel untouched.
-static void launch_plan(cafe_sketch *s, int n, int &rounds, bool &big) {
+static void launch_plan(cafe_sketch *s, int n, int &rounds, bool &big, bool &big_hot) {
     const int max_rounds = std::min(std::max(s->opt_max_rounds, 1), kMaxRounds) + 1;
     const DevState *fb = reinterpret_cast<const DevState *>(s->h_pinned);
     rounds = max_rounds;
     big = true;
+    big_hot = true;
     if (s->last_seen_batch != n) {         // other batch size: forget what was learnt
         for (int &h : s->hint_rounds) h = 0;
         s->last_seen_batch = n;
@@ -1044,6 +1259,7 @@ static void launch_plan(cafe_sketch *s, int n, int &rounds, bool &big) {
     for (int h : s->hint_rounds) { known += h > 0; most = std::max(most, h); }
     if (known >= 4) rounds = std::min(max_rounds, most + 2);
     if (known >= 4 && fb->maxpart > 0 && (long)fb->maxpart * 3 / 2 + kCapEv <= kCapSmall) big = false;
+    if (known >= 4 && (long)fb->pad[3] * 3 / 2 <= kCapHot) big_hot = false;
 }
 
 int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st) {
@@ -1057,28 +1273,48 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     w.call_seq++;
     const unsigned long long tag = w.call_seq;
     Ctl *ctl = w.zr.as<Ctl>();
-    uint32_t *cnt = w.zr.as<uint32_t>() + kCtlWords, *evcnt = cnt + g.P1 + g.P2;
+    uint32_t *cnt = w.zr.as<uint32_t>() + kCtlWords, *evcnt = cnt + g.P1 + g.P2, *cnth = evcnt + 2 * g.P1;
     uint32_t *off = w.off.as<uint32_t>();
     uint32_t *rank1 = w.rank.as<uint32_t>(), *rank2 = rank1 + n;
-    Rec *rec1 = w.items.as<Rec>(), *rec2 = rec1 + n;
+    Rec *rec1 = w.items.as<Rec>(), *rec2 = rec1 + n, *rech = rec2 + n;
+    unsigned long long *hkey = w.hkey.as<unsigned long long>();
+    float *hrun = w.hrun.as<float>();
+    int2 *hfin = w.hfin.as<int2>();
     uint32_t *stage_tot = w.stage_tot.as<uint32_t>();
     const int gb = (n + 255) / 256;
-    hipLaunchKernelGGL(k_assign, dim3((n + kAssignChunk - 1) / kAssignChunk), dim3(1024), 4 * (size_t)(g.P1 + g.P2), st, g,
-                       d_ids, cnt, rank1, rank2);
-    hipLaunchKernelGGL(k_offsets, dim3(2), dim3(1024), 0, st, g, cnt, off, ctl, s->d_state);
-    hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, g, d_ids, d_scores, off, rank1, rank2, rec1, rec2);
+    hipLaunchKernelGGL(k_assign, dim3((n + kAssignChunk - 1) / kAssignChunk), dim3(1024),
+                       4 * (size_t)(g.P1 + g.P2 + (g.hot ? g.P1 : 0)), st, g, s->d_main, d_ids, cnt, cnth, rank1, rank2);
+    hipLaunchKernelGGL(k_offsets, dim3(g.hot ? 3 : 2), dim3(1024), 0, st, g, cnt, cnth, off, ctl, s->d_state);
+    hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, g, d_ids, d_scores, off, rank1, rank2, rec1, rec2, rech);
     int rounds;
-    bool big;
-    launch_plan(s, n, rounds, big);
+    bool big, big_hot;
+    launch_plan(s, n, rounds, big, big_hot);
+    if (g.hot) {
+        // The bypass is independent of round 1 (its results are first read by round 2's move handling and by the
+        // finish kernels), so it runs beside round 1 on a stream of its own.
+        hipStream_t hs = s->side_stream ? s->side_stream : st;
+        if (hs != st) {
+            CAFE_HIP_CHECK(hipEventRecord(s->ev_fork, st));
+            CAFE_HIP_CHECK(hipStreamWaitEvent(hs, s->ev_fork, 0));
+        }
+        hipLaunchKernelGGL((k_hot_chain<kCapHot, false>), dim3(g.P1), dim3(kThreads), 0, hs, g, s->d_main, s->d_state, ctl, off,
+                           rech, hkey, hrun, hfin, w.miss.as<uint8_t>(), w.outm.as<uint8_t>());
+        if (big_hot)
+            hipLaunchKernelGGL((k_hot_chain<kCapBig, true>), dim3(g.P1), dim3(kThreads), 0, hs, g, s->d_main, s->d_state, ctl, off,
+                               rech, hkey, hrun, hfin, w.miss.as<uint8_t>(), w.outm.as<uint8_t>());
+        if (hs != st) CAFE_HIP_CHECK(hipEventRecord(s->ev_join, hs));
+    }
 #define CAFE_MAIN(CAPV, BIGV)                                                                                              \
     hipLaunchKernelGGL((k_main_round<CAPV, BIGV>), dim3(g.P1), dim3(kThreads), 0, st, g, r, tag, s->d_main, s->d_state, ctl, \
                        off, rec1, evcnt, w.ev.as<MoveEv>(), w.evres.as<EvRes>(), w.miss.as<uint8_t>(),    \
-                       w.outm.as<uint8_t>(), w.stage_m.as<MainBucket>(), stage_tot, w.prevcnt.as<uint32_t>(), w.ldirty.as<uint8_t>())
+                       w.outm.as<uint8_t>(), w.stage_m.as<MainBucket>(), stage_tot, w.prevcnt.as<uint32_t>(), w.ldirty.as<uint8_t>(), \
+                       hkey, hrun)
 #define CAFE_LRU(CAPV, BIGV)                                                                                               \
     hipLaunchKernelGGL((k_lru_round<CAPV, BIGV>), dim3(g.P2), dim3(kThreads), 0, st, g, r, s->d_lru, s->d_state, ctl, \
                        off, rec2, w.miss.as<uint8_t>(), evcnt, w.ev.as<MoveEv>(), w.outl.as<uint8_t>(),          \
                        w.stage_l.as<LruBucket>(), stage_tot, w.ldirty.as<uint8_t>(), w.myev.as<MoveEv>(), w.mycnt.as<uint32_t>())
     for (int r = 1; r <= rounds; ++r) {
+        if (r == 2 && g.hot && s->side_stream) CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_join, 0));
         CAFE_MAIN(kCapSmall, false);
         if (big) CAFE_MAIN(kCapBig, true);
         CAFE_LRU(kCapSmall, false);
@@ -1086,6 +1322,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     }
 #undef CAFE_MAIN
 #undef CAFE_LRU
+    if (rounds < 2 && g.hot && s->side_stream) CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_join, 0));
     const int nb = (n + kScanBlock - 1) / kScanBlock;
     uint8_t *flags = w.flags.as<uint8_t>();
     int32_t *pushval = (int32_t *)(flags + (((size_t)n + 15) & ~(size_t)15));
@@ -1098,7 +1335,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     const int cb = std::min(g.P1 + g.P2, 2048);
     hipLaunchKernelGGL(k_commit, dim3(cb), dim3(256), 0, st, g, s->d_main, s->d_lru, s->d_fifo, s->fifo_cap, s->d_state, ctl,
                        off, stage_tot, w.stage_m.as<MainBucket>(), w.stage_l.as<LruBucket>(), flags, pushval, poprank,
-                       pushrank, clkrank);
+                       pushrank, clkrank, hfin);
     CAFE_HIP_CHECK(hipGetLastError());
     // closing kernel: applies the batch totals to the device scalars, or, for a batch the owners could not settle,
     // runs it in order from the untouched tables
@@ -1111,7 +1348,8 @@ void par_free(cafe_sketch *s) {
     if (!s->par) return;
     ParWorkspace &w = *s->par;
     DevBuf *all[] = {&w.zr, &w.off, &w.rank, &w.items, &w.ev, &w.evres, &w.miss, &w.outm, &w.outl,
-                     &w.stage_m, &w.stage_l, &w.stage_tot, &w.prevcnt, &w.ldirty, &w.myev, &w.mycnt, &w.flags, &w.blocksum, &w.ranks};
+                     &w.stage_m, &w.stage_l, &w.stage_tot, &w.prevcnt, &w.ldirty, &w.myev, &w.mycnt, &w.flags, &w.blocksum, &w.ranks,
+                     &w.hkey, &w.hrun, &w.hfin};
     for (DevBuf *b : all) b->release();
     delete s->par;
     s->par = nullptr;

@@ -50,7 +50,7 @@ struct cafe_sketch {
     // upper bound of real_n known to the host without a sync (each inserted id raises real_n by at most 1)
     long long real_n_ub = 0;
     // options / counters
-    int opt_serial = 0, opt_max_rounds = 6, opt_target_items = 224;
+    int opt_serial = 0, opt_max_rounds = 6, opt_target_items = 320, opt_hot_bypass = 1;
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // workspaces
     cafe::DevBuf ws_reset_keys, ws_reset_keys2, ws_reset_tmp, ws_reset_flags, ws_misc;
@@ -58,6 +58,8 @@ struct cafe_sketch {
     int32_t *h_pinned = nullptr;    // pinned host mirror of DevState, written by the kernel that closes every insert
     int32_t *d_pinned = nullptr;    // the same memory as the device sees it
     hipStream_t last_stream = nullptr;
+    hipStream_t side_stream = nullptr;   // the hot bypass runs beside round 1 of the owners
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int hint_rounds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // final round counts of recent calls (0 = unknown)
     int hint_pos = 0;
     long long last_seen_batch = -1;

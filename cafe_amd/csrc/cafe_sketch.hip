@@ -372,7 +372,8 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     cafe_sketch *s = new cafe_sketch();
     CAFE_HIP_CHECK(hipGetDevice(&s->device));
     s->lim = lim; s->adjust = adjust_thres; s->alpha = alpha; s->lru_first = lru_first ? 1 : 0;
-    if (const char *e = getenv("CAFE_TARGET_ITEMS")) s->opt_target_items = std::max(16, atoi(e));   // tuning aid
+    if (const char *e = getenv("CAFE_TARGET_ITEMS")) s->opt_target_items = std::max(16, atoi(e));   // tuning aids
+    if (const char *e = getenv("CAFE_HOT_BYPASS")) s->opt_hot_bypass = atoi(e) ? 1 : 0;
     s->n1 = (int)(lim * 0.9);           // sketch.cpp:51-52
     s->n2 = (int)(lim * 0.1);
     s->fifo_cap = (uint32_t)lim;
@@ -383,6 +384,11 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     CAFE_HIP_CHECK(hipHostMalloc((void **)&s->h_pinned, 256, hipHostMallocMapped));
     memset(s->h_pinned, 0, 256);
     CAFE_HIP_CHECK(hipHostGetDevicePointer((void **)&s->d_pinned, s->h_pinned, 0));
+    // measured on cfg3: the bypass kernel and round 1 are both limited by LDS residency, so running them side by side
+    // gains nothing; the side stream stays an opt-in
+    if (getenv("CAFE_SIDE_STREAM")) CAFE_HIP_CHECK(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
     if (s->ws_misc.reserve(4096)) return 1;
     CAFE_HIP_CHECK(hipMemset(s->d_main, 0, sizeof(MainBucket) * (size_t)s->n1));
     CAFE_HIP_CHECK(hipMemset(s->d_lru, 0, sizeof(LruBucket) * (size_t)s->n2));
@@ -399,6 +405,9 @@ extern "C" int cafe_sketch_destroy(cafe_sketch_t *s) {
     par_free(s);
     (void)hipFree(s->d_main); (void)hipFree(s->d_lru); (void)hipFree(s->d_fifo); (void)hipFree(s->d_state);
     if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+    if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     s->ws_reset_keys.release(); s->ws_reset_keys2.release(); s->ws_reset_tmp.release();
     s->ws_reset_flags.release(); s->ws_misc.release();
     delete s;
@@ -409,6 +418,7 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
     if (!strcmp(name, "serial_insert")) s->opt_serial = value;
     else if (!strcmp(name, "max_rounds")) s->opt_max_rounds = value < 1 ? 1 : value;
     else if (!strcmp(name, "target_items")) s->opt_target_items = value < 16 ? 16 : value;
+    else if (!strcmp(name, "hot_bypass")) s->opt_hot_bypass = value ? 1 : 0;
     else { set_error("unknown option %s", name); return 1; }
     return 0;
 }

@@ -74,6 +74,36 @@ def test_fresh_streams_match_oracle(lim, thr, batch, calls, space, oracle_mod):
     assert not oracle_mod.states_equal(sk.state(), ora.state())
 
 
+@pytest.mark.parametrize("bypass", [1, 0], ids=["hot_bypass", "owners_only"])
+@pytest.mark.parametrize("lim,thr,batch,calls,space,a", [
+    (300, 3, 2048, 30, 1500, 1.1),        # tiny table: every bucket mixes hot ids, cold ids and incoming moves
+    (1200, 6, 8192, 12, 20000, 1.3),      # heavy ids (hundreds of items each) next to LRU churn
+    (4000, 2, 4096, 16, 6000, 1.01),      # low threshold: promotions into buckets that hold hot slots, resets
+])
+def test_hot_ids_and_moves_share_buckets(lim, thr, batch, calls, space, a, bypass, oracle_mod):
+    """Ids that are hot before a batch bypass the owner rounds (ordered sums only); a move that lands in their bucket
+    must still see their score as of its position in the batch (sketch.cpp:244-258).  Half the scores are large so that
+    evicted LRU entries qualify for a move (score >= 5, sketch.cpp:193-195)."""
+    from cafe_amd.sketch import HotSketch
+    ora = oracle_mod.Oracle(lim, thr, 1, 1.0000005, 1)
+    sk = HotSketch(lim, thr, 1, 1.0000005, 1)
+    sk.set_option("hot_bypass", bypass)
+    rng = np.random.default_rng(77)
+    for c in range(calls):
+        ids = np.where(rng.random(batch) < 0.6, (rng.zipf(a, size=batch) - 1) % space + 1,
+                       rng.integers(1, space + 1, size=batch)).astype(np.int64)
+        v = (rng.random(batch, dtype=np.float32) * np.float32(2.0)).astype(np.float32)
+        v[rng.random(batch) < 0.3] *= np.float32(6.0)
+        want = ora.insert_val(ids, v)
+        got = sk.insert_val(ids, v).cpu().numpy()
+        assert np.array_equal(got, want), f"call {c}: ins differs"
+        bad = oracle_mod.states_equal(sk.state(), ora.state())
+        assert not bad, f"call {c}: " + "; ".join(bad[:3])
+    st = ora.stats()
+    assert st["evict_move"] + st["promote"] > 50 and st["main_hit"] > batch      # moves and hot hits really happened
+    assert sk.counters()["inorder_calls"] <= calls // 3
+
+
 def test_empty_and_tiny_batches(oracle_mod):
     from cafe_amd.sketch import HotSketch
     ora = oracle_mod.Oracle(100, 2, 1, 1.0, 1)
