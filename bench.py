@@ -162,9 +162,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    # CAFE_BENCH_REHEARSE=1: all ranks share cuda:0 and talk over gloo, to rehearse the N > 1 code path on a
+    # one-GPU box (the number it prints is not a scaling measurement)
+    rehearse = os.environ.get("CAFE_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     wl = workload(args.config, args.batch or None)
     F, B, D = wl.num_fields, wl.batch, wl.dim
     fused = not args.per_field_calls
@@ -212,7 +220,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if rehearse else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     fwd_ms = sum(a.elapsed_time(b) for a, b in zip(ev_f0, ev_f1)) / args.steps

@@ -90,6 +90,7 @@ class ShardedCafeEmbedding:
     def __init__(self, counts, dim, hotn, hash_sizes, offsets=None, threshold=500, adjust_thres=1, alpha=1.0000005, seed=0,
                  group=None, backend=None, device=None):
         self.group = group
+        self._host_staged = dist.get_backend(group) == "gloo"
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.counts = [int(c) for c in counts]
@@ -111,6 +112,14 @@ class ShardedCafeEmbedding:
     # -- exchange helpers ------------------------------------------------------------------------
     def _a2a(self, send, send_splits, recv_splits):
         out = send.new_empty((int(sum(recv_splits)),) + tuple(send.shape[1:]))
+        if send.is_cuda and self._host_staged:
+            # gloo has no device all-to-all: stage through the host (single-GPU rehearsals and tests only;
+            # on a node the backend is nccl = RCCL and buffers stay in HBM)
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(h_out, send.contiguous().cpu(), output_split_sizes=list(recv_splits),
+                                   input_split_sizes=list(send_splits), group=self.group)
+            out.copy_(h_out)
+            return out
         dist.all_to_all_single(out, send.contiguous(), output_split_sizes=list(recv_splits),
                                input_split_sizes=list(send_splits), group=self.group)
         return out
@@ -125,6 +134,8 @@ class ShardedCafeEmbedding:
         own = owner_of(gids, self.world)
         order = torch.argsort(own, stable=True)
         send_counts = torch.bincount(own, minlength=self.world)
+        if send_counts.is_cuda and self._host_staged:
+            send_counts = send_counts.cpu()
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         ss, rs = send_counts.tolist(), recv_counts.tolist()                          # split sizes live on the host
