@@ -192,16 +192,8 @@ def main():
     grad = torch.randn(F, B, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5 + rank))
     out = torch.empty(F, B, D, device="cuda")
 
-    ev_f0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev_f1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-
     def step(i, timed_idx=None):
-        ids = ids_dev[i % nb]
-        if timed_idx is not None:
-            ev_f0[timed_idx].record()
-        eng.forward(ids, out=out)
-        if timed_idx is not None:
-            ev_f1[timed_idx].record()
+        eng.forward(ids_dev[i % nb], out=out)
         eng.backward_update(grad, args.lr, per_field_calls=not fused)
 
     it = 0
@@ -223,20 +215,48 @@ def main():
         t = torch.tensor([dt], device="cpu" if rehearse else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    fwd_ms = sum(a.elapsed_time(b) for a, b in zip(ev_f0, ev_f1)) / args.steps
+
+    # roofline of the bandwidth kernels (N = 1): the library records HIP events around them on the stream they are
+    # launched on; measured in a few extra steps behind the timed region
+    kern = None
+    if world == 1:
+        import ctypes
+        L = eng.L
+        L.cafe_tables_set_timing(eng.tables, 1)
+        acc = [0.0, 0.0]
+        reps = 10
+        ms = ctypes.c_float()
+        for _ in range(reps):
+            step(it); it += 1
+            for k in range(2):
+                L.cafe_tables_kernel_ms(eng.tables, k, ctypes.byref(ms))
+                acc[k] += ms.value
+        L.cafe_tables_set_timing(eng.tables, 0)
+        kern = [a / reps for a in acc]
 
     if rank == 0:
         lookups = F * B * world * args.steps
         value = lookups / dt
-        # dominant kernel: the fused query+gather (k_forward).  Algorithmic bytes per lookup in that kernel
-        # (SURVEY.md 8(d)): id 4 + bucket probe 52 + selected row 4D + output row 4D.
-        fwd_bytes = F * B * (56 + 8 * D) if world == 1 else None
         roof = None
         if world == 1:
-            ach = fwd_bytes / (fwd_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_forward (fused sketch query + hot/cold row gather)",
-                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": None, "avg_launch_us": round(fwd_ms * 1e3, 2),
+            # algorithmic bytes per lookup (no credit for duplicate ids):
+            #   k_forward      id 4 + bucket probe 52 + selected row 4D + output row 4D
+            #   k_bwd_segments output gradient 4D + table row read-modify-write 8D
+            names = ["k_forward (fused sketch query + hot/cold row gather)", "k_bwd_segments (segment sums + SGD row update)"]
+            per_lookup = [56 + 8 * D, 12 * D]
+            dom = 0 if kern[0] >= kern[1] else 1
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic.json")       # PMC FETCH_SIZE/WRITE_SIZE of the same command
+            if os.path.exists(tp):
+                tj = json.load(open(tp))
+                if tj.get("workload") == f"{wl.name}/b{B}":
+                    traffic = tj.get(names[dom].split(" ")[0])
+            ach = F * B * per_lookup[dom] / (kern[dom] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": names[dom], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_us": round(kern[dom] * 1e3, 2),
+                    "algorithmic_bytes_per_launch": F * B * per_lookup[dom],
+                    "other_kernel": {"kernel": names[1 - dom], "avg_launch_us": round(kern[1 - dom] * 1e3, 2),
+                                     "achieved": round(F * B * per_lookup[1 - dom] / (kern[1 - dom] * 1e-3) / 1e9, 1)},
                     "whole_step_frac": round(value * wl.bytes_per_lookup() / 1e9 / HBM_PEAK_GBS, 4)}
         res = {
             "metric": "embedding lookups/sec (fwd+bwd+sketch)", "value": round(value, 1), "unit": "lookups/s",

@@ -44,6 +44,8 @@ SYMBOLS = {
     "cafe_tables_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp,
                                           ctypes.POINTER(_vp), _i64p, _i32p]),
     "cafe_tables_destroy": (ctypes.c_int, [_vp]),
+    "cafe_tables_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "cafe_tables_kernel_ms": (ctypes.c_int, [_vp, ctypes.c_int, _f32p]),
     "cafe_forward_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "cafe_scores_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "cafe_migrate_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),

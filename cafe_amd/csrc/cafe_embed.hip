@@ -41,9 +41,27 @@ extern "C" int cafe_tables_create(cafe_tables_t **out, int num_fields, int dim, 
     return 0;
 }
 
+extern "C" int cafe_tables_set_timing(cafe_tables_t *t, int on) {
+    if (on && !t->ev_t[0][0])
+        for (int k = 0; k < 2; ++k)
+            for (int j = 0; j < 2; ++j) CAFE_HIP_CHECK(hipEventCreate(&t->ev_t[k][j]));
+    t->timing = on ? 1 : 0;
+    return 0;
+}
+
+extern "C" int cafe_tables_kernel_ms(cafe_tables_t *t, int which, float *ms) {
+    if (which < 0 || which > 1 || !t->ev_t[which][0]) { set_error("cafe_tables_kernel_ms: timing was not enabled"); return 1; }
+    CAFE_HIP_CHECK(hipEventSynchronize(t->ev_t[which][1]));
+    CAFE_HIP_CHECK(hipEventElapsedTime(ms, t->ev_t[which][0], t->ev_t[which][1]));
+    return 0;
+}
+
 extern "C" int cafe_tables_destroy(cafe_tables_t *t) {
     if (!t) return 0;
     (void)hipDeviceSynchronize();
+    for (int k = 0; k < 2; ++k)
+        for (int j = 0; j < 2; ++j)
+            if (t->ev_t[k][j]) (void)hipEventDestroy(t->ev_t[k][j]);
     (void)hipFree(t->d_w_cold); (void)hipFree(t->d_id_offset); (void)hipFree(t->d_hash_size); (void)hipFree(t->d_cold_base);
     t->ws_norm.release(); t->ws_bwd_a.release(); t->ws_bwd_b.release(); t->ws_bwd_c.release(); t->ws_bwd_d.release();
     t->ws_misc.release();
@@ -132,6 +150,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
 #define CAFE_FWD(L)                                                                                              \
     hipLaunchKernelGGL(k_forward<L>, dim3(blocks), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold,     \
                        t->d_id_offset, t->d_hash_size, d_local_ids, d_in_gids, d_fields, batch, total, t->dim, d_gids, d_que, d_out)
+    if (t->timing) (void)hipEventRecord(t->ev_t[0][0], st);
     switch (lpg) {
         case 1: CAFE_FWD(1); break;
         case 2: CAFE_FWD(2); break;
@@ -142,6 +161,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
         default: CAFE_FWD(64); break;
     }
 #undef CAFE_FWD
+    if (t->timing) (void)hipEventRecord(t->ev_t[0][1], st);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -602,6 +622,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
 #define CAFE_SEG(L, V)                                                                                                   \
     hipLaunchKernelGGL((k_bwd_segments<L, V>), dim3(max_tiles), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
                        t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr)
+    if (t->timing) (void)hipEventRecord(t->ev_t[1][0], st);
     if (vpl == 1) {
         switch (lpg) {
             case 1: CAFE_SEG(1, 1); break;
@@ -618,6 +639,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         CAFE_SEG(64, 4);
     }
 #undef CAFE_SEG
+    if (t->timing) (void)hipEventRecord(t->ev_t[1][1], st);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -75,6 +75,9 @@ struct cafe_tables {
     int64_t *d_cold_base = nullptr;  // device array [F+1]: first row of field f in the unified cold row space
     int64_t total_cold_rows = 0;
     cafe::DevBuf ws_norm, ws_bwd_a, ws_bwd_b, ws_bwd_c, ws_bwd_d, ws_misc;
+    // optional HIP-event timing of the two bandwidth kernels (bench.py's roofline figures): [0] k_forward, [1] k_bwd_segments
+    int timing = 0;
+    hipEvent_t ev_t[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
 };
 
 namespace cafe {

@@ -104,6 +104,11 @@ int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const float *d_score
 int cafe_tables_create(cafe_tables_t **out, int num_fields, int dim, int hotn, float *d_w_hot,
                        float *const *d_w_cold, const int64_t *id_offset, const int32_t *hash_size);
 int cafe_tables_destroy(cafe_tables_t *t);
+/* Measurement aid (no reference counterpart): when on, HIP events are recorded on the caller's stream around the two
+ * bandwidth kernels of the path; cafe_tables_kernel_ms waits for and returns the last launch's duration.
+ * which: 0 = fused query+gather (cafe_forward*_dev), 1 = segment-sum + SGD (cafe_backward_sgd*_dev). */
+int cafe_tables_set_timing(cafe_tables_t *t, int on);
+int cafe_tables_kernel_ms(cafe_tables_t *t, int which, float *ms);
 
 /* sk_embedding_bag.py:101-113 (query) + 119-152 (forward), all fields in one launch.
  * d_local_ids: [num_fields, batch] int64 per-field ids (the reference's lS_i, one index per bag);
