@@ -62,6 +62,7 @@ extern "C" int cafe_tables_destroy(cafe_tables_t *t) {
     for (int k = 0; k < 2; ++k)
         for (int j = 0; j < 2; ++j)
             if (t->ev_t[k][j]) (void)hipEventDestroy(t->ev_t[k][j]);
+    if (t->ev_plan) (void)hipEventDestroy(t->ev_plan);
     (void)hipFree(t->d_w_cold); (void)hipFree(t->d_id_offset); (void)hipFree(t->d_hash_size); (void)hipFree(t->d_cold_base);
     t->ws_norm.release(); t->ws_bwd_a.release(); t->ws_bwd_b.release(); t->ws_bwd_c.release(); t->ws_bwd_d.release();
     t->ws_misc.release();
@@ -593,8 +594,10 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
     BWD_STAMP(2);
 }
 
+// The backward in two parts: the partition passes (they read the routing only) on `pst`, the segment kernel (gradient
+// rows in, table rows updated) on `st`.  With pst != st the caller orders st behind t->ev_plan, recorded here on pst.
 static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,
-                           int batch, int total, float lr, hipStream_t st) {
+                           int batch, int total, float lr, hipStream_t st, hipStream_t pst, int part = 3) {
     if (total <= 0) return 0;
     const int64_t rows = (int64_t)t->hotn + t->total_cold_rows;
     if (rows >= (int64_t)0xFFFFFFFFLL) { set_error("cafe_backward_sgd_dev: more than 2^32 table rows"); return 1; }
@@ -614,11 +617,20 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     uint32_t *cnt = t->ws_bwd_a.as<uint32_t>(), *off = t->ws_bwd_b.as<uint32_t>();
     uint32_t *rank = t->ws_bwd_c.as<uint32_t>(), *keys = rank + total;
     unsigned long long *items = t->ws_bwd_d.as<unsigned long long>();
-    hipLaunchKernelGGL(k_bwd_assign, dim3((total + kBwdChunk - 1) / kBwdChunk), dim3(1024), 4 * (size_t)P, st, P, d_fields, d_que,
-                       t->d_hash_size, t->d_cold_base, t->hotn, batch, total, cnt, rank, keys);
     uint32_t *tiles = t->ws_misc.as<uint32_t>();
-    hipLaunchKernelGGL(k_bwd_offsets, dim3(1), dim3(1024), 0, st, P, cnt, off, tiles);
-    hipLaunchKernelGGL(k_bwd_scatter, dim3((std::max(total, P) + 255) / 256), dim3(256), 0, st, P, total, keys, rank, off, cnt, items);
+    if (part & 1) {
+        hipLaunchKernelGGL(k_bwd_assign, dim3((total + kBwdChunk - 1) / kBwdChunk), dim3(1024), 4 * (size_t)P, pst, P, d_fields,
+                           d_que, t->d_hash_size, t->d_cold_base, t->hotn, batch, total, cnt, rank, keys);
+        hipLaunchKernelGGL(k_bwd_offsets, dim3(1), dim3(1024), 0, pst, P, cnt, off, tiles);
+        hipLaunchKernelGGL(k_bwd_scatter, dim3((std::max(total, P) + 255) / 256), dim3(256), 0, pst, P, total, keys, rank, off,
+                           cnt, items);
+        if (pst != st) {
+            if (!t->ev_plan) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_plan, hipEventDisableTiming));
+            CAFE_HIP_CHECK(hipEventRecord(t->ev_plan, pst));
+        }
+    }
+    if (!(part & 2)) { CAFE_HIP_CHECK(hipGetLastError()); return 0; }
+    if (pst != st) CAFE_HIP_CHECK(hipStreamWaitEvent(st, t->ev_plan, 0));
 #define CAFE_SEG(L, V)                                                                                                   \
     hipLaunchKernelGGL((k_bwd_segments<L, V>), dim3(max_tiles), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
                        t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr)
@@ -647,12 +659,13 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
 extern "C" int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_que,
                                      const float *d_grad_out, int batch, float lr, cafe_stream_t stream) {
     (void)d_gids;
-    return backward_common(t, nullptr, d_que, d_grad_out, batch, t->num_fields * batch, lr, (hipStream_t)stream);
+    return backward_common(t, nullptr, d_que, d_grad_out, batch, t->num_fields * batch, lr, (hipStream_t)stream,
+                           (hipStream_t)stream);
 }
 
 extern "C" int cafe_backward_sgd_gid_dev(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que,
                                          const float *d_grad_out, int n, float lr, cafe_stream_t stream) {
-    return backward_common(t, d_fields, d_que, d_grad_out, 1, n, lr, (hipStream_t)stream);
+    return backward_common(t, d_fields, d_que, d_grad_out, 1, n, lr, (hipStream_t)stream, (hipStream_t)stream);
 }
 
 // scores -> one batch_insert_val over all fields -> migration -> backward + SGD, in the reference's order
@@ -661,8 +674,21 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
                                         const int32_t *d_que, const float *d_grad_out, int batch, float lr, float *d_scores,
                                         int32_t *d_ins, cafe_stream_t stream) {
     const int total = t->num_fields * batch;
+    hipStream_t st = (hipStream_t)stream;
+    // What does not depend on this step's gradients runs on the sketch's second stream, beside the score kernels and
+    // the owner rounds: the head of the insert (per-call scalars, partition counts: ids and pre-batch tables only)
+    // and the partition passes of the backward (routing of the forward only).  Everything that was queued on `stream`
+    // before this call (the previous step's commit and SGD, this step's forward) is ordered before them.
+    hipStream_t side = s->opt_overlap && s->side_stream && s->side_stream != st ? s->side_stream : st;
+    if (side != st) {
+        CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, st));
+        CAFE_HIP_CHECK(hipStreamWaitEvent(side, s->ev_head_fork, 0));
+    }
     if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
-    if (cafe_insert_dev(s, d_gids, d_scores, total, d_ins, stream)) return 1;
+    const bool plan_first = (s->opt_overlap & 4) != 0;
+    if (plan_first && side != st && backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 1)) return 1;
+    if (cafe::insert_dev_on(s, d_gids, d_scores, total, d_ins, st, (s->opt_overlap & 1) ? side : st)) return 1;
+    if (!plan_first && side != st && backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 1)) return 1;
     if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, 0, t->num_fields, stream)) return 1;
-    return cafe_backward_sgd_dev(t, d_gids, d_que, d_grad_out, batch, lr, stream);
+    return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, side != st ? 2 : 3);
 }

@@ -1262,10 +1262,15 @@ static void launch_plan(cafe_sketch *s, int n, int &rounds, bool &big, bool &big
     if (known >= 4 && (long)fb->pad[3] * 3 / 2 <= kCapHot) big_hot = false;
 }
 
-int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st) {
+int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st,
+               hipStream_t pre) {
     Geo g;
     if (n > (1 << 21)) {     // the 23-bit time field of the owners' sort key
         s->counters[2]++;
+        if (pre != st) {
+            CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, pre));
+            CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));
+        }
         return launch_serial_insert(s, d_ids, d_scores, n, d_ins, 0, st);
     }
     if (ensure_ws(s, n, g)) return 1;      // sized by par_prepare already; the prologue kernel zeroed w.zr
@@ -1283,8 +1288,12 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     uint32_t *stage_tot = w.stage_tot.as<uint32_t>();
     const int gb = (n + 255) / 256;
     hipLaunchKernelGGL(k_assign, dim3((n + kAssignChunk - 1) / kAssignChunk), dim3(1024),
-                       4 * (size_t)(g.P1 + g.P2 + (g.hot ? g.P1 : 0)), st, g, s->d_main, d_ids, cnt, cnth, rank1, rank2);
-    hipLaunchKernelGGL(k_offsets, dim3(g.hot ? 3 : 2), dim3(1024), 0, st, g, cnt, cnth, off, ctl, s->d_state);
+                       4 * (size_t)(g.P1 + g.P2 + (g.hot ? g.P1 : 0)), pre, g, s->d_main, d_ids, cnt, cnth, rank1, rank2);
+    hipLaunchKernelGGL(k_offsets, dim3(g.hot ? 3 : 2), dim3(1024), 0, pre, g, cnt, cnth, off, ctl, s->d_state);
+    if (pre != st) {         // the scores come in here
+        CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, pre));
+        CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));
+    }
     hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, g, d_ids, d_scores, off, rank1, rank2, rec1, rec2, rech);
     int rounds;
     bool big, big_hot;
@@ -1292,7 +1301,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     if (g.hot) {
         // The bypass is independent of round 1 (its results are first read by round 2's move handling and by the
         // finish kernels), so it runs beside round 1 on a stream of its own.
-        hipStream_t hs = s->side_stream ? s->side_stream : st;
+        hipStream_t hs = s->hot_on_side ? s->side_stream : st;
         if (hs != st) {
             CAFE_HIP_CHECK(hipEventRecord(s->ev_fork, st));
             CAFE_HIP_CHECK(hipStreamWaitEvent(hs, s->ev_fork, 0));
@@ -1314,7 +1323,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
                        off, rec2, w.miss.as<uint8_t>(), evcnt, w.ev.as<MoveEv>(), w.outl.as<uint8_t>(),          \
                        w.stage_l.as<LruBucket>(), stage_tot, w.ldirty.as<uint8_t>(), w.myev.as<MoveEv>(), w.mycnt.as<uint32_t>())
     for (int r = 1; r <= rounds; ++r) {
-        if (r == 2 && g.hot && s->side_stream) CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_join, 0));
+        if (r == 2 && g.hot && s->hot_on_side) CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_join, 0));
         CAFE_MAIN(kCapSmall, false);
         if (big) CAFE_MAIN(kCapBig, true);
         CAFE_LRU(kCapSmall, false);
@@ -1322,7 +1331,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     }
 #undef CAFE_MAIN
 #undef CAFE_LRU
-    if (rounds < 2 && g.hot && s->side_stream) CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_join, 0));
+    if (rounds < 2 && g.hot && s->hot_on_side) CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_join, 0));
     const int nb = (n + kScanBlock - 1) / kScanBlock;
     uint8_t *flags = w.flags.as<uint8_t>();
     int32_t *pushval = (int32_t *)(flags + (((size_t)n + 15) & ~(size_t)15));

@@ -58,8 +58,13 @@ struct cafe_sketch {
     int32_t *h_pinned = nullptr;    // pinned host mirror of DevState, written by the kernel that closes every insert
     int32_t *d_pinned = nullptr;    // the same memory as the device sees it
     hipStream_t last_stream = nullptr;
-    hipStream_t side_stream = nullptr;   // the hot bypass runs beside round 1 of the owners
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // Second stream of the handle.  The part of an insert that does not need the scores (per-call scalars, reset,
+    // partition counts and offsets) and the partition passes of the backward run there, beside the score kernels and
+    // the owner rounds on the caller's stream (cafe_backward_update_dev).  With CAFE_SIDE_STREAM set the hot bypass
+    // runs there too, beside round 1 of the owners.
+    hipStream_t side_stream = nullptr;
+    int hot_on_side = 1, opt_overlap = 3;     // measured: 0.318 ms per cfg3 step against 0.330 with one stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_head_fork = nullptr, ev_head_join = nullptr;
     int hint_rounds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // final round counts of recent calls (0 = unknown)
     int hint_pos = 0;
     long long last_seen_batch = -1;
@@ -78,15 +83,22 @@ struct cafe_tables {
     // optional HIP-event timing of the two bandwidth kernels (bench.py's roofline figures): [0] k_forward, [1] k_bwd_segments
     int timing = 0;
     hipEvent_t ev_t[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipEvent_t ev_plan = nullptr;    // partition passes of the backward done (recorded on the sketch's side stream)
 };
 
 namespace cafe {
 // cafe_insert_par.hip
-int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st);
+// `pre`: stream for the kernels that do not read the scores (== st: everything in order on st)
+int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st,
+               hipStream_t pre);
 // region the per-call prologue kernel has to zero for a parallel insert of n ids (nullptr: none)
 int par_prepare(cafe_sketch *s, int n, uint32_t **zero, int *zero_words);
 void par_free(cafe_sketch *s);
 // cafe_sketch.hip
 int launch_serial_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
                          int only_if_fallback, hipStream_t st, const uint32_t *par_totals = nullptr);
+// cafe_insert_dev with the score-independent head on `pre`; the caller has made `pre` wait for whatever of `st` the head
+// depends on (the previous insert, the ids) and may have queued the score kernels on `st` behind that point
+int insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st,
+                  hipStream_t pre);
 }  // namespace cafe

@@ -386,9 +386,13 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     CAFE_HIP_CHECK(hipHostGetDevicePointer((void **)&s->d_pinned, s->h_pinned, 0));
     // measured on cfg3: the bypass kernel and round 1 are both limited by LDS residency, so running them side by side
     // gains nothing; the side stream stays an opt-in
-    if (getenv("CAFE_SIDE_STREAM")) CAFE_HIP_CHECK(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
+    CAFE_HIP_CHECK(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
+    if (const char *e = getenv("CAFE_SIDE_STREAM")) s->hot_on_side = atoi(e);
+    if (const char *e = getenv("CAFE_OVERLAP")) s->opt_overlap = atoi(e);
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_fork, hipEventDisableTiming));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_join, hipEventDisableTiming));
     if (s->ws_misc.reserve(4096)) return 1;
     CAFE_HIP_CHECK(hipMemset(s->d_main, 0, sizeof(MainBucket) * (size_t)s->n1));
     CAFE_HIP_CHECK(hipMemset(s->d_lru, 0, sizeof(LruBucket) * (size_t)s->n2));
@@ -408,6 +412,8 @@ extern "C" int cafe_sketch_destroy(cafe_sketch_t *s) {
     if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->ev_head_fork) (void)hipEventDestroy(s->ev_head_fork);
+    if (s->ev_head_join) (void)hipEventDestroy(s->ev_head_join);
     s->ws_reset_keys.release(); s->ws_reset_keys2.release(); s->ws_reset_tmp.release();
     s->ws_reset_flags.release(); s->ws_misc.release();
     delete s;
@@ -638,7 +644,11 @@ extern "C" int cafe_query_dev(cafe_sketch_t *s, const int32_t *d_ids, int n, int
 
 extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
                                cafe_stream_t stream) {
-    hipStream_t st = (hipStream_t)stream;
+    return insert_dev_on(s, d_ids, d_scores, n, d_ins, (hipStream_t)stream, (hipStream_t)stream);
+}
+
+int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st,
+                        hipStream_t pre) {
     if (n < 0) { set_error("cafe_insert_dev: negative length"); return 1; }
     // sketch.cpp:282-289
     s->batch_num++;
@@ -649,7 +659,12 @@ extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const flo
     uint32_t *zero = nullptr;
     int zero_words = 0;
     if (parallel && par_prepare(s, n, &zero, &zero_words)) return 1;
-    hipLaunchKernelGGL(k_prologue, dim3(1), dim3(1024), 0, st, s->d_state, flip_now, s->flip, zero, zero_words);
+    if (!parallel && pre != st) {           // in-order kernel: nothing to run beside the scores
+        CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, pre));
+        CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));
+        pre = st;
+    }
+    hipLaunchKernelGGL(k_prologue, dim3(1), dim3(1024), 0, pre, s->d_state, flip_now, s->flip, zero, zero_words);
     // sketch.cpp:291.  real_n after the previous insert was copied to pinned memory behind that insert; waiting
     // for that copy (normally long done: later kernels of the step were queued behind it) gives the exact value.
     if (s->adjust && (double)s->real_n_ub > s->lim * 1.2) {
@@ -659,7 +674,7 @@ extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const flo
             s->real_n_ub = reinterpret_cast<const volatile DevState *>(s->h_pinned)->real_n;
         }
         if ((double)s->real_n_ub > s->lim * 1.2) {
-            if (run_reset(s, st)) return 1;
+            if (run_reset(s, pre)) return 1;
             s->real_n_ub = s->lim;
         }
     }
@@ -670,7 +685,7 @@ extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const flo
         rc = launch_serial_insert(s, d_ids, d_scores, n, d_ins, 0, st);
         s->counters[2]++;
     } else {
-        rc = par_insert(s, d_ids, d_scores, n, d_ins, st);
+        rc = par_insert(s, d_ids, d_scores, n, d_ins, st, pre);
     }
     s->real_n_ub += n;        // upper bound until the readback below is consumed
     if (rc == 0) {
