@@ -19,6 +19,7 @@ SYMBOLS = {
     "cafe_version": (ctypes.c_int, []),
     "init": (None, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
     "batch_query": (_i32p, [_u32p, ctypes.c_int]),
+    "batch_query_median": (_i32p, [_u32p, ctypes.c_int]),
     "batch_insert": (_i32p, [_u32p, ctypes.c_int]),
     "batch_insert_val": (_i32p, [_u32p, _f32p, ctypes.c_int]),
     "analyse": (ctypes.c_double, [_u32p, ctypes.c_int]),
@@ -40,6 +41,7 @@ SYMBOLS = {
     "cafe_sketch_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
     "cafe_sketch_counters": (ctypes.c_int, [_vp, _i64p]),
     "cafe_query_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "cafe_query_median_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "cafe_insert_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
     "cafe_tables_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp,
                                           ctypes.POINTER(_vp), _i64p, _i32p]),
@@ -47,6 +49,7 @@ SYMBOLS = {
     "cafe_tables_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cafe_tables_kernel_ms": (ctypes.c_int, [_vp, ctypes.c_int, _f32p]),
     "cafe_forward_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "cafe_forward_ml_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cafe_scores_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "cafe_migrate_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "cafe_backward_sgd_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_float, _vp]),

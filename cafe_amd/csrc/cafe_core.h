@@ -292,4 +292,21 @@ __device__ inline int32_t query_bucket(const int32_t val[kSlots], const int32_t 
     return (int32_t)x;
 }
 
+// Median tier of tricks/sketch_ml_embed.py (:66-67, :82-84, :148-152) -- a definition, the reference has no such
+// function in any sketch.cpp: -x when query() does not report x hot and the main table holds it without a hot slot
+// at a score (pending lazy decay applied, read-only) of at least 0.2 * Threshold; +x otherwise.
+__device__ inline int32_t median_bucket(const int32_t val[kSlots], const int32_t dic[kSlots], const float cnt[kSlots],
+                                        uint32_t bflip, int gflip, float thr, uint32_t x) {
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i)
+        if ((uint32_t)val[i] == x && dic[i]) return (int32_t)x;           // hot
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i)
+        if ((uint32_t)val[i] == x && !dic[i]) {
+            const float c = (bflip & 1u) != (uint32_t)(gflip & 1) ? decay_once(cnt[i]) : cnt[i];
+            return (double)c >= 0.2 * (double)thr ? -(int32_t)x : (int32_t)x;
+        }
+    return (int32_t)x;
+}
+
 }  // namespace cafe

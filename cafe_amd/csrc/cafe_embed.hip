@@ -81,7 +81,9 @@ static inline int lanes_per_row(int dim) {
 // LPG lanes cooperate on one lookup: every lane probes the same 32-B val|dic half bucket (one request
 // per group), then the group copies the selected row as float4 per lane (coalesced 16 B/lane).
 // ------------------------------------------------------------------------------------------------
-template <int LPG>
+// ML = the three-tier variant of tricks/sketch_ml_embed.py:154-199: a cold lookup of medium importance adds the row
+// of a second hash table (W_median[gid % median_n]) to its cold row.
+template <int LPG, bool ML = false>
 __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ mt, FastMod fm1,
                                                  const float *__restrict__ w_hot, float *const *__restrict__ w_cold,
                                                  const int64_t *__restrict__ id_offset, const int32_t *__restrict__ hash_size,
@@ -89,7 +91,9 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
                                                  const int32_t *__restrict__ in_gids, const int32_t *__restrict__ fields,
                                                  int batch, int total, int dim,
                                                  int32_t *__restrict__ gids, int32_t *__restrict__ que,
-                                                 float *__restrict__ out) {
+                                                 float *__restrict__ out, const float *__restrict__ w_med = nullptr,
+                                                 int median_n = 1, const DevState *__restrict__ st = nullptr, int gflip = 0,
+                                                 int32_t *__restrict__ qmed = nullptr) {
     // A wave takes 64 consecutive lookups.  First every lane resolves one lookup on its own (id, one 32-B probe of
     // val|dic, routing, source row address): three dependent memory steps for 64 lookups instead of per lookup.  Then
     // the wave copies the 64 rows, 64/LPG rows per instruction (LPG lanes x float4 = one row), eight instructions in
@@ -102,6 +106,7 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
     for (int base = wave * 64; base < total; base += waves * 64) {
         const int i = base + lane;
         const float *row = nullptr;
+        const float *row2 = nullptr;
         if (i < total) {
             const int f = fields ? fields[i] : i / batch;
             const int32_t g = local_ids ? (int32_t)(local_ids[i] + id_offset[f]) : in_gids[i];      // sk_embedding_bag.py:103
@@ -114,9 +119,18 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
             row = q < 0 ? w_hot + (size_t)(-q) * dim : w_cold[f] + (size_t)((uint32_t)q % (uint32_t)hash_size[f]) * dim;
             if (gids) gids[i] = g;
             que[i] = q;
+            if constexpr (ML) {
+                const int4 cw = p[2];
+                const float cnt[4] = {__int_as_float(cw.x), __int_as_float(cw.y), __int_as_float(cw.z), __int_as_float(cw.w)};
+                const int32_t m = median_bucket(val, dic, cnt, (uint32_t)p[3].x, gflip, st->thr, x);
+                qmed[i] = m;
+                if (m < 0) row2 = w_med + (size_t)(x % (uint32_t)median_n) * dim;
+            }
         }
         const unsigned long long ra = (unsigned long long)row;
         const int lo = (int)(uint32_t)ra, hi = (int)(uint32_t)(ra >> 32);
+        const unsigned long long rb = (unsigned long long)row2;
+        const int lo2 = (int)(uint32_t)rb, hi2 = (int)(uint32_t)(rb >> 32);
         const int nrow = min(64, total - base);
         float4 *obase = reinterpret_cast<float4 *>(out + (size_t)base * dim);
         for (int c0 = 0; c0 < dim4; c0 += LPG) {
@@ -128,6 +142,13 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
                     const int r = j + u * RPI + sub;
                     const unsigned long long a = ((unsigned long long)(uint32_t)__shfl(hi, r & 63, 64) << 32) | (uint32_t)__shfl(lo, r & 63, 64);
                     t[u] = (r < nrow && c < dim4) ? reinterpret_cast<const float4 *>(a)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (ML) {
+                        const unsigned long long a2 = ((unsigned long long)(uint32_t)__shfl(hi2, r & 63, 64) << 32) | (uint32_t)__shfl(lo2, r & 63, 64);
+                        if (r < nrow && c < dim4 && a2) {
+                            const float4 m = reinterpret_cast<const float4 *>(a2)[c];
+                            t[u].x += m.x; t[u].y += m.y; t[u].z += m.z; t[u].w += m.w;
+                        }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -149,8 +170,9 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     const int blocks = (int)std::min<long>(((long)total + 255) / 256, 256 * 16);      // a wave per 64 lookups
     FastMod fm1 = make_fastmod(s->n1);
 #define CAFE_FWD(L)                                                                                              \
-    hipLaunchKernelGGL(k_forward<L>, dim3(blocks), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold,     \
-                       t->d_id_offset, t->d_hash_size, d_local_ids, d_in_gids, d_fields, batch, total, t->dim, d_gids, d_que, d_out)
+    hipLaunchKernelGGL((k_forward<L, false>), dim3(blocks), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold, \
+                       t->d_id_offset, t->d_hash_size, d_local_ids, d_in_gids, d_fields, batch, total, t->dim, d_gids, d_que, \
+                       d_out, (const float *)nullptr, 1, (const DevState *)nullptr, 0, (int32_t *)nullptr)
     if (t->timing) (void)hipEventRecord(t->ev_t[0][0], st);
     switch (lpg) {
         case 1: CAFE_FWD(1); break;
@@ -163,6 +185,37 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     }
 #undef CAFE_FWD
     if (t->timing) (void)hipEventRecord(t->ev_t[0][1], st);
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int cafe_forward_ml_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, int batch,
+                                   const float *d_w_median, int median_n, int32_t *d_gids, int32_t *d_que, int32_t *d_qmed,
+                                   float *d_out, cafe_stream_t stream) {
+    const long total_l = (long)t->num_fields * batch;
+    if (total_l == 0) return 0;
+    if (batch <= 0 || total_l > 0x7fffffffL / 4 || median_n <= 0 || !d_w_median || !d_qmed) {
+        set_error("cafe_forward_ml_dev: bad arguments");
+        return 1;
+    }
+    const int total = (int)total_l;
+    const int blocks = (int)std::min<long>(((long)total + 255) / 256, 256 * 16);
+    FastMod fm1 = make_fastmod(s->n1);
+    hipStream_t st = (hipStream_t)stream;
+#define CAFE_FWD(L)                                                                                                        \
+    hipLaunchKernelGGL((k_forward<L, true>), dim3(blocks), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold,      \
+                       t->d_id_offset, t->d_hash_size, d_local_ids, nullptr, nullptr, batch, total, t->dim, d_gids, d_que, \
+                       d_out, d_w_median, median_n, s->d_state, s->flip, d_qmed)
+    switch (lanes_per_row(t->dim)) {
+        case 1: CAFE_FWD(1); break;
+        case 2: CAFE_FWD(2); break;
+        case 4: CAFE_FWD(4); break;
+        case 8: CAFE_FWD(8); break;
+        case 16: CAFE_FWD(16); break;
+        case 32: CAFE_FWD(32); break;
+        default: CAFE_FWD(64); break;
+    }
+#undef CAFE_FWD
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }

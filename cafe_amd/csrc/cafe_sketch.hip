@@ -80,6 +80,16 @@ __global__ void k_query(const MainBucket *__restrict__ mt, int n1, const int32_t
     que[i] = query_bucket(val, dic, x);
 }
 
+// batch_query_median of tricks/sketch_ml_embed.py:82-84 (defined in cafe_core.h::median_bucket)
+__global__ void k_query_median(const MainBucket *__restrict__ mt, int n1, const DevState *__restrict__ st, int gflip,
+                               const int32_t *__restrict__ ids, int n, int32_t *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = (uint32_t)ids[i];
+    const MainBucket &b = mt[hash_main(x, n1)];
+    out[i] = median_bucket(b.val, b.dic, b.cnt, b.flip, gflip, st->thr, x);
+}
+
 // sketch.cpp:321-327 / 142-150: present in the main table at all (hot or not)
 __global__ void k_count(const MainBucket *__restrict__ mt, int n1, const int32_t *__restrict__ ids, int n,
                         int mode, unsigned long long *out) {
@@ -642,6 +652,14 @@ extern "C" int cafe_query_dev(cafe_sketch_t *s, const int32_t *d_ids, int n, int
     return 0;
 }
 
+extern "C" int cafe_query_median_dev(cafe_sketch_t *s, const int32_t *d_ids, int n, int32_t *d_out, cafe_stream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_query_median, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_main, s->n1, s->d_state,
+                       s->flip, d_ids, n, d_out);
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
                                cafe_stream_t stream) {
     return insert_dev_on(s, d_ids, d_scores, n, d_ins, (hipStream_t)stream, (hipStream_t)stream);
@@ -736,6 +754,17 @@ extern "C" int *batch_query(uint32_t *data, int len) {
     die_if(cafe_query_dev(g_sk, g_d_ids.as<int32_t>(), len, g_d_out.as<int32_t>(), nullptr), "batch_query");
     die_if(hipMemcpy(g_que.data(), g_d_out.p, (size_t)len * 4, hipMemcpyDeviceToHost) != hipSuccess, "batch_query copy");
     return g_que.data();
+}
+
+extern "C" int *batch_query_median(uint32_t *data, int len) {
+    static std::vector<int> med;
+    die_if(g_sk == nullptr, "batch_query_median before init");
+    med.resize((size_t)std::max(len, 1));
+    if (len <= 0) return med.data();
+    die_if(stage(data, nullptr, len), "batch_query_median");
+    die_if(cafe_query_median_dev(g_sk, g_d_ids.as<int32_t>(), len, g_d_out.as<int32_t>(), nullptr), "batch_query_median");
+    die_if(hipMemcpy(med.data(), g_d_out.p, (size_t)len * 4, hipMemcpyDeviceToHost) != hipSuccess, "batch_query_median copy");
+    return med.data();
 }
 
 static int *insert_common(uint32_t *data, float *v, int len) {

@@ -45,6 +45,11 @@ int *batch_query(uint32_t *data, int len);
 int *batch_insert(uint32_t *data, int len);
 /* sketch.cpp:306-308 / 281-296. */
 int *batch_insert_val(uint32_t *data, float *v, int len);
+/* Bound by tricks/sketch_ml_embed.py:82-84 (MLEmbeddingBag's median tier) but exported by no sketch.cpp of the
+ * reference -- defined here (parity unpinned): out[i] = -data[i] when the id is not hot, sits in the main table
+ * without a hot slot and its score (pending lazy decay applied, read-only) is >= 0.2 * Threshold
+ * (threshold2 = 0.2 * threshold1, sketch_ml_embed.py:66-67); +data[i] otherwise.  The module reads "< 0" (:151). */
+int *batch_query_median(uint32_t *data, int len);
 /* sketch.cpp:314-320 and 321-327. */
 double analyse(uint32_t *data, int len);
 double analyse1(uint32_t *data, int len);
@@ -94,6 +99,8 @@ int cafe_sketch_counters(cafe_sketch_t *s, int64_t *out8);
 
 /* sketch.cpp:260-265 batch_query: d_que[i] = -slot if d_ids[i] holds a hot slot, else d_ids[i]. */
 int cafe_query_dev(cafe_sketch_t *s, const int32_t *d_ids, int n, int32_t *d_que, cafe_stream_t stream);
+/* batch_query_median (group A) on device pointers. */
+int cafe_query_median_dev(cafe_sketch_t *s, const int32_t *d_ids, int n, int32_t *d_out, cafe_stream_t stream);
 /* sketch.cpp:281-296 batch_insert_val (d_scores != NULL) / 266-280 batch_insert (NULL): exactly the
  * state and d_ins[] that the reference's in-order loop produces for this batch. */
 int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
@@ -117,6 +124,13 @@ int cafe_tables_kernel_ms(cafe_tables_t *t, int which, float *ms);
  * d_out:       [num_fields, batch, dim] float32 = hot ? W_hot[slot] : W_cold[f][gid % hash_size[f]]. */
 int cafe_forward_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, int batch,
                      int32_t *d_gids, int32_t *d_que, float *d_out, cafe_stream_t stream);
+
+/* sketch_ml_embed.py:154-199, the three-tier forward, in one launch: as cafe_forward_dev, plus
+ * d_qmed out [num_fields*batch] = batch_query_median of d_gids, and a cold lookup of medium importance adds
+ * d_w_median[gid % median_n] ([median_n, dim] float32, shared by all fields like the hot table) to its cold row. */
+int cafe_forward_ml_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, int batch,
+                        const float *d_w_median, int median_n, int32_t *d_gids, int32_t *d_que, int32_t *d_qmed,
+                        float *d_out, cafe_stream_t stream);
 
 /* sk_embedding_bag.py:178-189 with the intended semantics: d_scores[f*batch+i] =
  * ||g_i|| * batch / sum_j ||g_j|| over field f.  d_grad_out: [num_fields, batch, dim]. */

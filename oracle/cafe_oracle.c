@@ -251,6 +251,29 @@ void cafe_oracle_batch_query(const cafe_oracle_t *o, const uint32_t *ids, int le
     for (int i = 0; i < len; ++i) que[i] = query_one(o, ids[i]);
 }
 
+/* Median tier of tricks/sketch_ml_embed.py.  The module binds lib.batch_query_median (:82-84) and reads "< 0" as
+ * "medium importance" (:148-152), with threshold2 = 0.2 * threshold1 (:66-67); no sketch.cpp in the reference exports
+ * the function, so this is a DEFINITION, not a restatement (parity unpinned): an id reads -id when query() does not
+ * report it hot and the main table holds it without a hot slot at a score -- pending lazy decay applied, read-only --
+ * of at least 0.2 * Threshold; +id otherwise. */
+void cafe_oracle_batch_query_median(const cafe_oracle_t *o, const uint32_t *ids, int len, int32_t *out) {
+    for (int i = 0; i < len; ++i) {
+        uint32_t x = ids[i];
+        int32_t r = (int32_t)x;
+        if (query_one(o, x) >= 0) {
+            int key = hash_main(o, x);
+            for (int s = 0; s < W; ++s) {
+                if ((uint32_t)o->mval[key * W + s] != x || o->mdic[key * W + s]) continue;
+                float c = o->mcnt[key * W + s];
+                if (o->mflip[key] != (uint8_t)o->flip) c = (float)((double)c / DECAY_V);
+                if ((double)c >= 0.2 * (double)o->thr) r = -(int32_t)x;
+                break;
+            }
+        }
+        out[i] = r;
+    }
+}
+
 /* sketch.cpp:314-320 */
 double cafe_oracle_analyse(const cafe_oracle_t *o, const uint32_t *ids, int len) {
     int hot = 0;

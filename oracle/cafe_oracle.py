@@ -43,6 +43,7 @@ def _lib():
         L.cafe_oracle_destroy.argtypes = [ctypes.c_void_p]
         L.cafe_oracle_batch_insert_val.argtypes = [ctypes.c_void_p, _u32p, _f32p, ctypes.c_int, _i32p]
         L.cafe_oracle_batch_query.argtypes = [ctypes.c_void_p, _u32p, ctypes.c_int, _i32p]
+        L.cafe_oracle_batch_query_median.argtypes = [ctypes.c_void_p, _u32p, ctypes.c_int, _i32p]
         L.cafe_oracle_analyse.restype = ctypes.c_double
         L.cafe_oracle_analyse.argtypes = [ctypes.c_void_p, _u32p, ctypes.c_int]
         L.cafe_oracle_analyse1.restype = ctypes.c_double
@@ -92,6 +93,13 @@ class Oracle:
         que = np.zeros(len(ids), dtype=np.int32)
         self.L.cafe_oracle_batch_query(self.h, ids.ctypes.data_as(_u32p), len(ids), que.ctypes.data_as(_i32p))
         return que
+
+    def query_median(self, ids):
+        """Median tier of sketch_ml_embed.py (a definition, see cafe_oracle.c): -id = medium importance."""
+        ids = _ids(ids)
+        out = np.zeros(len(ids), dtype=np.int32)
+        self.L.cafe_oracle_batch_query_median(self.h, ids.ctypes.data_as(_u32p), len(ids), out.ctypes.data_as(_i32p))
+        return out
 
     def analyse(self, ids):
         ids = _ids(ids)
@@ -186,6 +194,16 @@ def ref_forward(que, w_hot, w_cold, hash_size):
     dic = np.abs(que)
     out = np.where(hot[:, None], w_hot[dic % w_hot.shape[0]], w_cold[dic % hash_size])
     return out.astype(np.float32), hot
+
+
+def ref_forward_ml(que, qmed, w_hot, w_cold, w_med, hash_size, median_n):
+    """sketch_ml_embed.py:166-197: hot ? W_h[|que| % hotn] : W_hash[|que| % hash_size] + (median ? W_med[|que| % median_n] : 0)."""
+    que = np.asarray(que)
+    dic = np.abs(que).astype(np.int64)
+    hot = (que < 0)[:, None]
+    med = (np.asarray(qmed) < 0)[:, None]
+    low = w_cold[dic % hash_size] + np.where(med, w_med[dic % median_n], np.float32(0))
+    return np.where(hot, w_hot[dic % w_hot.shape[0]], low).astype(np.float32)
 
 
 def ref_scores(grad_out):
