@@ -73,6 +73,21 @@ def reset_sketch_time():
     _sketch_ms = 0.0
 
 
+def sketch_state_dict():
+    """Complete state of the global sketch behind `lib` (every slot, scalars, free list) as CPU tensors and Python
+    scalars: what the reference's checkpoint should carry in `sketch_buffer` (dlrm_s_pytorch.py:443, never filled
+    there).  Store it next to model.state_dict(); restore with load_sketch_state_dict after lib.init(...)."""
+    from .sketch import HotSketch
+    return HotSketch.from_global().state_tensors()
+
+
+def load_sketch_state_dict(state):
+    """Inverse of sketch_state_dict; makes the lib.update() the reference calls on load (:1510-1511) unnecessary
+    (the free list is part of the state), though calling it stays harmless."""
+    from .sketch import HotSketch
+    HotSketch.from_global().load_state_tensors(state)
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

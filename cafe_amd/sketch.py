@@ -42,10 +42,42 @@ class HotSketch:
         self.n1 = int(lim * 0.9)
         self.n2 = int(lim * 0.1)
 
+    @classmethod
+    def from_global(cls):
+        """A view of the process-global sketch that lib.init() created (reference ABI, sketch.cpp:297, :309-313);
+        it is not destroyed with this object."""
+        self = cls.__new__(cls)
+        self.L = _lib.load()
+        h = self.L.cafe_global_sketch()
+        if not h:
+            raise _lib.CafeError("no global sketch: call lib.init(hotn, threshold, adjust, alpha) first")
+        self.h = ctypes.c_void_p(h)
+        self._borrowed = True
+        dims = (ctypes.c_int32 * 4)()
+        _lib.check(self.L.cafe_sketch_dims(self.h, dims), "cafe_sketch_dims")
+        self.n1, self.n2, self.lim = int(dims[0]), int(dims[1]), int(dims[2])
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        return self
+
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and not getattr(self, "_borrowed", False):
             self.L.cafe_sketch_destroy(self.h)
-            self.h = None
+        self.h = None
+
+    def state_tensors(self):
+        """state() as CPU tensors and Python scalars: goes into a torch checkpoint next to the model's state_dict
+        and loads back with torch.load(weights_only=True).  The reference meant `sketch_buffer` for this
+        (dlrm_s_pytorch.py:443) but never fills it, so its checkpoints lose the sketch."""
+        out = {}
+        for k, v in self.state().items():
+            if isinstance(v, np.ndarray):
+                out[k] = torch.from_numpy(np.ascontiguousarray(v.astype(np.int64) if v.dtype == np.uint32 else v))
+            else:
+                out[k] = float(v) if isinstance(v, (float, np.floating)) else int(v)
+        return out
+
+    def load_state_tensors(self, st):
+        self.load_state_dict({k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in st.items()})
 
     def __del__(self):
         try:

@@ -62,15 +62,8 @@ def synthetic_batches(w, dense_dim, num_batches, seed, device):
 def save_checkpoint(path, model, step):
     """Model parameters + tables + the complete sketch state (every slot, scalars, free list)."""
     emb = model.embedding
-
-    def plain(v):           # tensors and Python scalars only: the file loads with torch.load(weights_only=True)
-        if isinstance(v, np.ndarray):
-            return torch.from_numpy(np.ascontiguousarray(v.astype(np.int64) if v.dtype == np.uint32 else v))
-        return float(v) if isinstance(v, (float, np.floating)) else int(v)
-
     torch.save({"step": int(step), "head": model.head.state_dict(), "weight_high": emb.weight_high.cpu(),
-                "weight_hash": [w.cpu() for w in emb.weight_hash],
-                "sketch": {k: plain(v) for k, v in emb.sketch.state().items()}}, path)
+                "weight_hash": [w.cpu() for w in emb.weight_hash], "sketch": emb.sketch.state_tensors()}, path)
 
 
 def load_checkpoint(path, model):
@@ -80,7 +73,7 @@ def load_checkpoint(path, model):
     emb.weight_high.copy_(ck["weight_high"])
     for w, src in zip(emb.weight_hash, ck["weight_hash"]):
         w.copy_(src)
-    emb.sketch.load_state_dict({k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in ck["sketch"].items()})
+    emb.sketch.load_state_tensors(ck["sketch"])
     return int(ck["step"])
 
 

@@ -80,3 +80,36 @@ def test_module_matches_reference_module(name):
         _close(weight_high.detach().cpu().numpy(), g[f"w_hot_{step}"], f"{name} step {step} hot table")
     assert get_sketch_time() > 0.0
     assert embs[0].query_dic.dtype == np.bool_ and embs[0].query_dic.shape == (B,)
+
+
+def test_sketch_state_travels_with_a_checkpoint(tmp_path):
+    """sketch_state_dict / load_sketch_state_dict: the global sketch through torch.save / torch.load(weights_only=True)
+    and lib.update() afterwards (dlrm_s_pytorch.py:1510-1511) leave queries and later inserts unchanged."""
+    import cafe_amd
+    from cafe_amd.sk_embedding_bag import sketch_state_dict, load_sketch_state_dict
+    from cafe_amd.sketch import HotSketch
+    lib = ctypes.CDLL(cafe_amd.LIB_PATH)
+    lib.init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    lib.init(500, 4, 1, 1.01)
+    rng = np.random.default_rng(8)
+    sk = HotSketch.from_global()
+    batches = [(rng.zipf(1.2, 400) % 5000 + 1).astype(np.int32) for _ in range(60)]
+    scores = [(rng.random(400) * 3).astype(np.float32) for _ in range(60)]
+    for b, v in zip(batches[:40], scores[:40]):
+        sk.insert_val(torch.from_numpy(b).cuda(), torch.from_numpy(v).cuda())
+    path = str(tmp_path / "ck.pt")
+    torch.save({"sketch": sketch_state_dict()}, path)
+    for b, v in zip(batches[40:], scores[40:]):
+        sk.insert_val(torch.from_numpy(b).cuda(), torch.from_numpy(v).cuda())
+    want = sk.state()
+    lib.init(500, 4, 1, 1.01)                                  # a fresh process would start here
+    load_sketch_state_dict(torch.load(path, weights_only=True)["sketch"])
+    lib.update()
+    sk = HotSketch.from_global()
+    for b, v in zip(batches[40:], scores[40:]):
+        sk.insert_val(torch.from_numpy(b).cuda(), torch.from_numpy(v).cuda())
+    got = sk.state()
+    for k in ("mval", "mdic", "mcnt", "lval", "ldic", "lcnt", "lt", "fifo"):
+        assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), k
+    for k in ("thr", "num", "real_n", "clk", "flip", "batch_num", "decay"):
+        assert got[k] == want[k], k
