@@ -38,7 +38,11 @@ def parse():
     ap.add_argument("--preheat", type=int, default=40, help="untimed steps that populate the sketch before warmup")
     ap.add_argument("--lr", type=float, default=0.1)
     ap.add_argument("--zipf-a", type=float, default=1.05, help="Zipf exponent of the id streams (<= 1: uniform ids; diagnostics)")
-    ap.add_argument("--per-field-calls", action="store_true", help="one batch_insert_val per field (reference loop)")
+    ap.add_argument("--per-field-calls", action="store_true",
+                    help="issue the reference's one batch_insert_val per field one by one (default: same sketch cadence, "
+                         "run as one insert per step whenever no flip or reset can fall between two fields)")
+    ap.add_argument("--one-call-per-step", action="store_true",
+                    help="ONE batch_insert_val per step over all fields' ids (decay and reset test once per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -175,7 +179,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     wl = workload(args.config, args.batch or None)
     F, B, D = wl.num_fields, wl.batch, wl.dim
-    fused = not args.per_field_calls
+    cadence = "loop" if args.per_field_calls else (False if args.one_call_per_step else True)
 
     if world == 1:
         from cafe_amd.collection import CafeEmbeddingCollection
@@ -194,7 +198,7 @@ def main():
 
     def step(i, timed_idx=None):
         eng.forward(ids_dev[i % nb], out=out)
-        eng.backward_update(grad, args.lr, per_field_calls=not fused)
+        eng.backward_update(grad, args.lr, per_field_calls=cadence)
 
     it = 0
     for _ in range(args.preheat + args.warmup):
@@ -265,7 +269,8 @@ def main():
             "data": "synthetic Zipf(1.05) ids, random-init tables, random upstream gradient",
             "config": {"workload": f"{wl.name}: {F} fields, {sum(wl.counts)} ids, D={D}, batch {B}/GPU, hotn {wl.hotn}, "
                                    f"compress {wl.compress_rate}, hash-rate {wl.hash_rate}, threshold {wl.threshold}",
-                       "sketch_calls": "one per step" if fused else "one per field",
+                       "sketch_calls": {True: "one per field (reference cadence), run as one insert per step",
+                                        "loop": "one per field, issued one by one", False: "one per step"}[cadence],
                        "parallelism": "single GPU" if world == 1 else f"id-hash sharded x{world}, RCCL all-to-all",
                        "preheat_steps": args.preheat},
             "sketch": eng.sketch.counters() if hasattr(eng, "sketch") else None,

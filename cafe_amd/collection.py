@@ -101,33 +101,30 @@ class CafeEmbeddingCollection:
     def backward_update(self, grad_out, lr, per_field_calls=True):
         """grad_out: [F, B, D] gradient of the loss w.r.t. forward's output.
 
-        per_field_calls=True feeds the sketch one batch_insert_val per field, exactly like the reference's
-        loop over fields (dlrm_s_pytorch.py:734-738); False issues one call for the whole step (same id
-        order, but decay/reset are evaluated once per step instead of once per field)."""
+        per_field_calls=True: the sketch sees one batch_insert_val per field, exactly like the reference's loop over
+        fields (dlrm_s_pytorch.py:734-738); the library still runs the step as one parallel insert whenever no flip
+        and no reset can fall between two fields (include/cafe_hip.h, cafe_backward_update_dev).  "loop": the same
+        calls issued one by one from here (test aid).  False: one call for the whole step (same id order, but decay
+        and reset are evaluated once per step instead of once per field)."""
         B, n = self._B, self.F * self._B
         grad_out = grad_out.contiguous()
         gids, que = self._buf["gids"], self._buf["que"]
         scores = self._get("scores", (n,), torch.float32)
         ins = self._get("ins", (n,), torch.int32)
         st = _stream()
-        if not per_field_calls:
+        if per_field_calls != "loop":
             _lib.check(self.L.cafe_backward_update_dev(self.sketch.h, self.tables, _ptr(self._ids), _ptr(gids), _ptr(que),
-                                                       _ptr(grad_out), B, ctypes.c_float(lr), _ptr(scores), _ptr(ins), st),
-                       "cafe_backward_update_dev")
+                                                       _ptr(grad_out), B, ctypes.c_float(lr), _ptr(scores), _ptr(ins),
+                                                       1 if per_field_calls else 0, st), "cafe_backward_update_dev")
             return scores, ins
         _lib.check(self.L.cafe_scores_dev(self.tables, _ptr(grad_out), B, _ptr(scores), st), "cafe_scores_dev")
-        if per_field_calls:
-            for f in range(self.F):
-                o = f * B * 4
-                _lib.check(self.L.cafe_insert_dev(self.sketch.h, ctypes.c_void_p(gids.data_ptr() + o),
-                                                  ctypes.c_void_p(scores.data_ptr() + o), B,
-                                                  ctypes.c_void_p(ins.data_ptr() + o), st), "cafe_insert_dev")
-                _lib.check(self.L.cafe_migrate_dev(self.sketch.h, self.tables, _ptr(self._ids), _ptr(gids), _ptr(ins), B,
-                                                   f, 1, st), "cafe_migrate_dev")
-        else:
-            _lib.check(self.L.cafe_insert_dev(self.sketch.h, _ptr(gids), _ptr(scores), n, _ptr(ins), st), "cafe_insert_dev")
+        for f in range(self.F):
+            o = f * B * 4
+            _lib.check(self.L.cafe_insert_dev(self.sketch.h, ctypes.c_void_p(gids.data_ptr() + o),
+                                              ctypes.c_void_p(scores.data_ptr() + o), B,
+                                              ctypes.c_void_p(ins.data_ptr() + o), st), "cafe_insert_dev")
             _lib.check(self.L.cafe_migrate_dev(self.sketch.h, self.tables, _ptr(self._ids), _ptr(gids), _ptr(ins), B,
-                                               0, self.F, st), "cafe_migrate_dev")
+                                               f, 1, st), "cafe_migrate_dev")
         _lib.check(self.L.cafe_backward_sgd_dev(self.tables, _ptr(gids), _ptr(que), _ptr(grad_out), B,
                                                 ctypes.c_float(lr), st), "cafe_backward_sgd_dev")
         return scores, ins

@@ -46,8 +46,21 @@ struct DevState {
     uint32_t fifo_head, fifo_len;
     int32_t flip, resets;
     // scratch written by kernels of the current call
-    int32_t maxpart, fallback, rounds, converged;    // maxpart: largest partition of the last parallel insert
+    int32_t maxpart, fallback, rounds;               // maxpart: largest partition of the last parallel insert
+    int32_t cadence_miss;    // cumulative: call boundaries at which sketch.cpp:291 would have reset but the host had not
     int32_t pad[4];
+    int32_t bad_commit;      // cumulative: staged entries the commit kernel refused (index out of range) -- always 0
+    int32_t pad2[3];
+};
+
+// What the kernel that closes an insert leaves in pinned host memory: the host reads it lagging, without a sync.
+constexpr int kMaxSeg = 64;
+struct Mirror {
+    DevState st;
+    uint32_t seq;       // sequence number of the insert call this snapshot closes
+    uint32_t n;         // ids of that call
+    uint32_t cross;     // threshold crossings (real_n growth) of that call
+    uint32_t pad;
 };
 
 __host__ __device__ inline int hash_main(uint32_t x, int n1) { return (int)((long long)x * kHashMul % n1); }

@@ -659,10 +659,8 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     if (vpl > 4) { set_error("cafe_backward_sgd_dev: dim %d too large", t->dim); return 1; }
     int P = std::max(1, std::min((total + kBwdTarget - 1) / kBwdTarget, kBwdMaxBins));
     const size_t cnt_bytes = 4 * (size_t)kBwdMaxBins + 16;
-    if (t->ws_bwd_a.cap < cnt_bytes) {                      // partition counters: zero once, kept zero by the scatter pass
-        if (t->ws_bwd_a.reserve(cnt_bytes)) return 1;
-        CAFE_HIP_CHECK(hipMemset(t->ws_bwd_a.p, 0, t->ws_bwd_a.cap));
-    }
+    // partition counters: zero from the allocation (DevBuf::reserve), kept zero by the scatter pass
+    if (t->ws_bwd_a.reserve(cnt_bytes)) return 1;
     const int max_tiles = P + total / kBwdCap + 1;
     if (t->ws_bwd_b.reserve(4 * (size_t)kBwdMaxBins + 16) || t->ws_norm.reserve(0) || t->ws_misc.reserve(4 * (size_t)max_tiles + 16) ||
         t->ws_bwd_c.reserve(8 * (size_t)total) ||
@@ -721,13 +719,48 @@ extern "C" int cafe_backward_sgd_gid_dev(cafe_tables_t *t, const int32_t *d_fiel
     return backward_common(t, d_fields, d_que, d_grad_out, 1, n, lr, (hipStream_t)stream, (hipStream_t)stream);
 }
 
-// scores -> one batch_insert_val over all fields -> migration -> backward + SGD, in the reference's order
-// (dlrm_s_pytorch.py:1642-1658), as one host call: at this point the host side is the bottleneck, not the GPU.
+// scores -> batch_insert_val -> migration -> backward + SGD, in the reference's order (dlrm_s_pytorch.py:1642-1658),
+// as one host call.
+// per_field != 0: the sketch is fed as the reference feeds it, one batch_insert_val per field (dlrm_s_pytorch.py:
+// 734-738): decay and batch counter advance once per field and sketch.cpp:291 is evaluated at every field boundary.
+// Without a flip or a reset on an inner boundary, F calls over consecutive parts of the id stream equal ONE in-order
+// pass over the whole stream, so the step still runs as one parallel insert; the host proves "no inner flip" from
+// its own counters and "no inner reset" from its bound on real_n (cafe_sketch.hip), the closing kernel re-checks
+// the boundaries against the real value (counter [6]).  A step that may hold an inner flip or reset is issued field
+// by field.  per_field == 0: one batch_insert_val for the whole step (decay and reset once per step).
 extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
                                         const int32_t *d_que, const float *d_grad_out, int batch, float lr, float *d_scores,
-                                        int32_t *d_ins, cafe_stream_t stream) {
-    const int total = t->num_fields * batch;
+                                        int32_t *d_ins, int per_field, cafe_stream_t stream) {
+    const int F = t->num_fields;
+    const int total = F * batch;
     hipStream_t st = (hipStream_t)stream;
+    bool fuse = true;
+    if (per_field && F > 1 && batch > 0) {
+        fuse = F <= kMaxSeg && s->opt_fuse_fields && !s->opt_serial;
+        double d = s->decay;
+        for (int f = 0; f < F && fuse; ++f) {           // sketch.cpp:284-289 for the F calls ahead
+            d *= s->alpha;
+            if (d > kDecayV) { d /= kDecayV; if (f > 0) fuse = false; }
+        }
+        if (fuse && s->adjust) {
+            const double at = s->lim * 1.2;
+            long long start = cafe::real_n_bound(s);
+            if ((double)(start + cafe::growth_estimate(s, total)) > at) {
+                if (cafe::real_n_exact(s, &start)) return 1;
+                if ((double)start > at) start = s->lim;                  // the first field's call begins with a reset
+                fuse = !((double)(start + cafe::growth_estimate(s, total)) > at);
+            }
+        }
+    }
+    if (!fuse) {
+        if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
+        for (int f = 0; f < F; ++f) {
+            const size_t o = (size_t)f * batch;
+            if (cafe_insert_dev(s, d_gids + o, d_scores + o, batch, d_ins + o, stream)) return 1;
+            if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, f, 1, stream)) return 1;
+        }
+        return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, st);
+    }
     // What does not depend on this step's gradients runs on the sketch's second stream, beside the score kernels and
     // the owner rounds: the head of the insert (per-call scalars, partition counts: ids and pre-batch tables only)
     // and the partition passes of the backward (routing of the forward only).  Everything that was queued on `stream`
@@ -740,7 +773,10 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
     if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
     const bool plan_first = (s->opt_overlap & 4) != 0;
     if (plan_first && side != st && backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 1)) return 1;
-    if (cafe::insert_dev_on(s, d_gids, d_scores, total, d_ins, st, (s->opt_overlap & 1) ? side : st)) return 1;
+    s->seg_len = per_field && F > 1 ? batch : 0;
+    const int rc = cafe::insert_dev_on(s, d_gids, d_scores, total, d_ins, st, (s->opt_overlap & 1) ? side : st);
+    s->seg_len = 0;
+    if (rc) return 1;
     if (!plan_first && side != st && backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 1)) return 1;
     if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, 0, t->num_fields, stream)) return 1;
     return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, side != st ? 2 : 3);

@@ -73,6 +73,7 @@ struct Ctl {                // zeroed at the start of every call
     uint32_t maxpart;       // largest owner partition (items) of this call
     uint32_t maxhot;        // largest hot-bypass partition
     uint32_t totals[8];     // pops, pushes, clock ticks, threshold crossings, rounds: applied by the closing kernel
+    uint32_t segcross[kMaxSeg];   // threshold crossings per segment of g.seg ids (a segment = one per-field reference call)
 };
 
 struct ParWorkspace {
@@ -82,6 +83,7 @@ struct ParWorkspace {
     DevBuf ldirty, myev, mycnt;
     DevBuf flags, blocksum, ranks;
     void *evres_seen = nullptr;
+    size_t evres_seen_cap = 0;
     unsigned long long call_seq = 0;
 };
 
@@ -90,6 +92,7 @@ struct Geo {
     int end_bit1, end_bit2;     // one past the highest key bit the owners' sorts have to look at
     int hot;                    // 1: ids that sit hot in the main table before the batch bypass the owner rounds
     uint32_t gflip;             // flip bit of this call (known on the host)
+    int seg;                    // > 0: ids per reference call when this call stands for several (cafe_backward_update_dev)
     FastMod fm1, fm2;
 };
 constexpr size_t kCtlWords = (sizeof(Ctl) + 3) / 4;
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(1024) k_assign(Geo g, const MainBucket *__rest
 
 // block 0: offsets of the main partitions, block 1: of the LRU partitions
 __global__ void __launch_bounds__(1024) k_offsets(Geo g, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ cnth,
-                                                  uint32_t *__restrict__ off, Ctl *ctl, const DevState *st) {
+                                                  uint32_t *__restrict__ off, Ctl *ctl, const DevState *st, int big, int big_hot) {
     __shared__ uint32_t sh[1024];
     __shared__ uint32_t carry;
     // block 0: main partitions, 1: LRU partitions, 2: hot-bypass partitions (offsets behind the other two)
@@ -254,6 +257,9 @@ __global__ void __launch_bounds__(1024) k_offsets(Geo g, const uint32_t *__restr
         int i = base + threadIdx.x;
         uint32_t v = i < P ? c[i] : 0u;
         if (v > (uint32_t)kCapBig) over = 1;
+        // the big-partition owners are only enqueued when recent calls needed them: a partition that would have no
+        // owner sends the batch to the in-order kernel (a main partition also takes up to kCapEv moves)
+        if (blockIdx.x == 2 ? (!big_hot && v > (uint32_t)kCapHot) : (!big && v + (blockIdx.x == 0 ? kCapEv : 0) > (uint32_t)kCapSmall)) over = 1;
         if (v > vmax) vmax = v;
         sh[threadIdx.x] = v;
         __syncthreads();
@@ -1037,6 +1043,7 @@ __global__ void __launch_bounds__(kScanBlock) k_finish_flags(
         ins[i] = got;
         pushval[i] = pv;
         flags[i] = (uint8_t)(pop | (push << 1) | (clk << 2));
+        if (cross && g.seg > 0) atomicAdd(&ctl->segcross[i / g.seg], 1u);      // a few hundred per call
     }
     // block totals (order inside the block is restored by the scan kernel)
     unsigned long long mp = __ballot(pop), mu = __ballot(push), mc = __ballot(clk), mx = __ballot(cross);
@@ -1110,9 +1117,11 @@ __global__ void __launch_bounds__(kScanBlock) k_finish_ranks(Geo g, int nblocks,
     }
 }
 
-__device__ inline int32_t resolve_dic(int32_t d, const uint32_t *fifo, uint32_t cap, uint32_t head, const uint32_t *poprank) {
+__device__ inline int32_t resolve_dic(int32_t d, const uint32_t *fifo, uint32_t cap, uint32_t head, const uint32_t *poprank,
+                                      uint32_t n = 0xffffffffu) {
     if ((uint32_t)d & kSur) {
         uint32_t pos = (uint32_t)d & ~kSur;
+        if (pos >= n) return 0;
         return (int32_t)fifo[(head + poprank[pos]) % cap];
     }
     return d;
@@ -1121,7 +1130,7 @@ __device__ inline int32_t resolve_dic(int32_t d, const uint32_t *fifo, uint32_t 
 // commit: staged buckets -> tables with placeholders resolved; pushes -> free list.
 // Workgroups walk the partitions' staging regions (main partitions, then LRU partitions), then the batch for pushes.
 __global__ void __launch_bounds__(256) k_commit(Geo g, MainBucket *mt, LruBucket *lt, uint32_t *fifo, uint32_t cap,
-                                                const DevState *st, const Ctl *ctl, const uint32_t *__restrict__ off,
+                                                DevState *st, const Ctl *ctl, const uint32_t *__restrict__ off,
                                                 const uint32_t *__restrict__ stage_tot, const MainBucket *__restrict__ stage_m,
                                                 const LruBucket *__restrict__ stage_l, const uint8_t *__restrict__ flags,
                                                 const int32_t *__restrict__ pushval, const uint32_t *__restrict__ poprank,
@@ -1132,16 +1141,22 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, MainBucket *mt, LruBucket
     const int32_t clk0 = st->clk;
     const int nparts = g.P1 + (ctl->final_round > 1 ? g.P2 : 0);      // round 1 final = nothing missed, no LRU work
     for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
-        const int tot = (int)stage_tot[part];
+        int tot = (int)stage_tot[part];
+        // Everything below indexes the tables with numbers read from the staging buffers.  They are written by the
+        // owners of this very call; the range checks turn a broken invariant into a counted refusal, not a wild store.
+        const int room = part < g.P1 ? (int)(off[part + 1] - off[part]) + kCapEv
+                                     : (int)(off[g.P1 + 2 + (part - g.P1)] - off[g.P1 + 1 + (part - g.P1)]);
+        if (tot < 0 || tot > room) { if (threadIdx.x == 0) atomicAdd(&st->bad_commit, 1); tot = 0; }
         if (part < g.P1) {
             const MainBucket *stage = stage_m + off[part] + (size_t)part * kCapEv;
             for (int s = threadIdx.x; s < tot; s += blockDim.x) {
                 const int4 *p = reinterpret_cast<const int4 *>(&stage[s]);
                 const int4 m = p[3];
                 if (m.y < 0) continue;
+                if (m.y >= g.n1) { atomicAdd(&st->bad_commit, 1); continue; }
                 int4 v = p[0], d = p[1], c = p[2];
-                d.x = resolve_dic(d.x, fifo, cap, head, poprank); d.y = resolve_dic(d.y, fifo, cap, head, poprank);
-                d.z = resolve_dic(d.z, fifo, cap, head, poprank); d.w = resolve_dic(d.w, fifo, cap, head, poprank);
+                d.x = resolve_dic(d.x, fifo, cap, head, poprank, (uint32_t)g.n); d.y = resolve_dic(d.y, fifo, cap, head, poprank, (uint32_t)g.n);
+                d.z = resolve_dic(d.z, fifo, cap, head, poprank, (uint32_t)g.n); d.w = resolve_dic(d.w, fifo, cap, head, poprank, (uint32_t)g.n);
                 int4 *o = reinterpret_cast<int4 *>(&mt[m.y]);
                 o[0] = v; o[1] = d; o[2] = c;
                 mt[m.y].flip = (uint32_t)m.x;
@@ -1157,6 +1172,7 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, MainBucket *mt, LruBucket
                 __syncthreads();
                 for (int s = threadIdx.x; s < nh; s += blockDim.x) {
                     const int2 f = hfin[oh0 + s];
+                    if (f.x >= 0 && (f.x >> 2) >= g.n1) { atomicAdd(&st->bad_commit, 1); continue; }
                     if (f.x >= 0) mt[f.x >> 2].cnt[f.x & 3] = __int_as_float(f.y);
                 }
             }
@@ -1167,8 +1183,10 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, MainBucket *mt, LruBucket
                 const int4 m = p[4];
                 if (m.y < 0) continue;
                 int4 v = p[0], d = p[1], c = p[2], t = p[3];
-                d.x = resolve_dic(d.x, fifo, cap, head, poprank); d.y = resolve_dic(d.y, fifo, cap, head, poprank);
-                d.z = resolve_dic(d.z, fifo, cap, head, poprank); d.w = resolve_dic(d.w, fifo, cap, head, poprank);
+                const long tmax = (long)clk0 + g.n;
+                if (m.y >= g.n2 || t.x > tmax || t.y > tmax || t.z > tmax || t.w > tmax) { atomicAdd(&st->bad_commit, 1); continue; }
+                d.x = resolve_dic(d.x, fifo, cap, head, poprank, (uint32_t)g.n); d.y = resolve_dic(d.y, fifo, cap, head, poprank, (uint32_t)g.n);
+                d.z = resolve_dic(d.z, fifo, cap, head, poprank, (uint32_t)g.n); d.w = resolve_dic(d.w, fifo, cap, head, poprank, (uint32_t)g.n);
                 if (t.x > clk0) t.x = clk0 + 1 + (int32_t)clkrank[t.x - clk0 - 1];
                 if (t.y > clk0) t.y = clk0 + 1 + (int32_t)clkrank[t.y - clk0 - 1];
                 if (t.z > clk0) t.z = clk0 + 1 + (int32_t)clkrank[t.z - clk0 - 1];
@@ -1183,7 +1201,7 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, MainBucket *mt, LruBucket
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += (long)gridDim.x * blockDim.x) {
         if (flags[i] & 2) {
             // pushes land behind everything the list held; pops only ever take what it held at the start
-            int32_t d = resolve_dic(pushval[i], fifo, cap, head, poprank);
+            int32_t d = resolve_dic(pushval[i], fifo, cap, head, poprank, (uint32_t)g.n);
             fifo[(unsigned long long)((unsigned long long)head + len0 + pushrank[i]) % cap] = (uint32_t)d;
         }
     }
@@ -1214,6 +1232,7 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     const int nblocks = (n + kScanBlock - 1) / kScanBlock;
     g.hot = s->opt_hot_bypass ? 1 : 0;
     g.gflip = (uint32_t)s->flip;
+    g.seg = s->seg_len > 0 && (n + s->seg_len - 1) / s->seg_len <= kMaxSeg ? s->seg_len : 0;
     if (w.zr.reserve(4 * (kCtlWords + PP + 3 * (size_t)g.P1) + 16) || w.off.reserve(4 * (PP + g.P1) + 32) || w.rank.reserve(8 * N) ||
         w.items.reserve(3 * sizeof(Rec) * N) || w.hkey.reserve(8 * N + 16) || w.hrun.reserve(4 * N + 16) || w.hfin.reserve(8 * N + 16) || w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * kCapEv) ||
         w.evres.reserve(sizeof(EvRes) * N) || w.miss.reserve(N) || w.outm.reserve(N) || w.outl.reserve(N) ||
@@ -1222,9 +1241,11 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
         w.myev.reserve(sizeof(MoveEv) * (size_t)g.P2 * kCapEvL) || w.mycnt.reserve(4 * (size_t)g.P2 + 4) || w.flags.reserve(5 * N + 64) ||
         w.blocksum.reserve(16 * (size_t)nblocks + 16) || w.ranks.reserve(12 * N))
         return 1;
-    if (w.evres.p != w.evres_seen) {      // tags of a fresh allocation must not match by accident
+    if (w.evres.p != w.evres_seen || w.evres.cap != w.evres_seen_cap) {      // tags of a fresh allocation must not match by accident
         CAFE_HIP_CHECK(hipMemset(w.evres.p, 0, w.evres.cap));
+        CAFE_HIP_CHECK(hipDeviceSynchronize());
         w.evres_seen = w.evres.p;
+        w.evres_seen_cap = w.evres.cap;
     }
     return 0;
 }
@@ -1289,15 +1310,16 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     const int gb = (n + 255) / 256;
     hipLaunchKernelGGL(k_assign, dim3((n + kAssignChunk - 1) / kAssignChunk), dim3(1024),
                        4 * (size_t)(g.P1 + g.P2 + (g.hot ? g.P1 : 0)), pre, g, s->d_main, d_ids, cnt, cnth, rank1, rank2);
-    hipLaunchKernelGGL(k_offsets, dim3(g.hot ? 3 : 2), dim3(1024), 0, pre, g, cnt, cnth, off, ctl, s->d_state);
+    int rounds;
+    bool big, big_hot;
+    launch_plan(s, n, rounds, big, big_hot);
+    hipLaunchKernelGGL(k_offsets, dim3(g.hot ? 3 : 2), dim3(1024), 0, pre, g, cnt, cnth, off, ctl, s->d_state, big ? 1 : 0,
+                       big_hot ? 1 : 0);
     if (pre != st) {         // the scores come in here
         CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, pre));
         CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));
     }
     hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, st, g, d_ids, d_scores, off, rank1, rank2, rec1, rec2, rech);
-    int rounds;
-    bool big, big_hot;
-    launch_plan(s, n, rounds, big, big_hot);
     if (g.hot) {
         // The bypass is independent of round 1 (its results are first read by round 2's move handling and by the
         // finish kernels), so it runs beside round 1 on a stream of its own.
@@ -1348,7 +1370,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     CAFE_HIP_CHECK(hipGetLastError());
     // closing kernel: applies the batch totals to the device scalars, or, for a batch the owners could not settle,
     // runs it in order from the untouched tables
-    if (launch_serial_insert(s, d_ids, d_scores, n, d_ins, 1, st, ctl->totals)) return 1;
+    if (launch_serial_insert(s, d_ids, d_scores, n, d_ins, 1, st, ctl->totals, ctl->segcross)) return 1;
     s->counters[1]++;
     return 0;
 }

@@ -48,7 +48,6 @@ struct cafe_sketch {
     uint32_t fifo_cap = 1;
     cafe::DevState *d_state = nullptr;
     // upper bound of real_n known to the host without a sync (each inserted id raises real_n by at most 1)
-    long long real_n_ub = 0;
     // options / counters
     int opt_serial = 0, opt_max_rounds = 6, opt_target_items = 320, opt_hot_bypass = 1;
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -68,7 +67,19 @@ struct cafe_sketch {
     int hint_rounds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // final round counts of recent calls (0 = unknown)
     int hint_pos = 0;
     long long last_seen_batch = -1;
-    bool real_n_pending = false;
+    // real_n as the host knows it without a sync: the last snapshot of the pinned mirror plus a growth estimate for the
+    // calls issued since (see real_n_bound in cafe_sketch.hip)
+    uint32_t call_seq = 0;              // sequence number of the insert being issued (0 = none yet)
+    uint32_t base_seq = 0;              // snapshots older than this are stale (a reset or a state import came later)
+    long long base_real_n = 0;          // real_n after call base_seq
+    double rates[32] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    int rate_pos = 0;                   // crossings per inserted id of the last 32 snapshots seen (1 = not seen yet)
+    uint32_t rate_seen_seq = 0;
+    int opt_fuse_fields = 1;
+    int opt_exact_reset = 0;            // 1: count every issued id as a possible crossing (waits more often, never guesses)
+    struct Issued { uint32_t seq; int n; };
+    Issued issued[64];                  // ring of the most recent calls
+    int seg_len = 0;                    // > 0: the call being issued stands for one reference call per seg_len ids
 };
 
 struct cafe_tables {
@@ -96,9 +107,13 @@ int par_prepare(cafe_sketch *s, int n, uint32_t **zero, int *zero_words);
 void par_free(cafe_sketch *s);
 // cafe_sketch.hip
 int launch_serial_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
-                         int only_if_fallback, hipStream_t st, const uint32_t *par_totals = nullptr);
+                         int only_if_fallback, hipStream_t st, const uint32_t *par_totals = nullptr,
+                         const uint32_t *segcross = nullptr);
 // cafe_insert_dev with the score-independent head on `pre`; the caller has made `pre` wait for whatever of `st` the head
 // depends on (the previous insert, the ids) and may have queued the score kernels on `st` behind that point
+long long growth_estimate(const cafe_sketch *s, long long n);
+long long real_n_bound(cafe_sketch *s);
+int real_n_exact(cafe_sketch *s, long long *out);
 int insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st,
                   hipStream_t pre);
 }  // namespace cafe

@@ -40,6 +40,10 @@ int DevBuf::reserve(size_t bytes) {
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
     size_t want = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;
     CAFE_HIP_CHECK(hipMalloc(&p, want));
+    // Workspaces start zeroed, and the zeros are in place before this returns: the kernels that use the buffer may run
+    // on any stream (the handles own a second one), a memset left pending on the null stream would race with them.
+    CAFE_HIP_CHECK(hipMemset(p, 0, want));
+    CAFE_HIP_CHECK(hipDeviceSynchronize());
     cap = want;
     return 0;
 }
@@ -120,7 +124,6 @@ __global__ void __launch_bounds__(1024) k_prologue(DevState *st, int flip_now, i
         st->flip = gflip;
         st->fallback = 0;
         st->rounds = 0;
-        st->converged = 0;
     }
 }
 
@@ -154,9 +157,23 @@ struct SerialCtx {
 __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket *lt, uint32_t *fifo, uint32_t cap,
                                                       DevState *st, int n1, int n2, const int32_t *__restrict__ ids,
                                                       const float *__restrict__ scores, int n, int32_t *__restrict__ ins,
-                                                      int only_if_fallback, const uint32_t *par_totals, DevState *host_mirror) {
+                                                      int only_if_fallback, const uint32_t *par_totals, Mirror *host_mirror,
+                                                      uint32_t seq, double reset_at, int seg, const uint32_t *segcross) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // sketch.cpp:291 is evaluated by the host from a bound on real_n (cafe_insert_dev).  Checked here against the real
+    // value: a call that should have begun with a reset, or -- for a call that stands for one call per `seg` ids --
+    // an inner boundary at which the per-field call would have, is counted, never silently accepted.
+    const int32_t real_n0 = st->real_n;
+    if ((double)real_n0 > reset_at) st->cadence_miss += 1;
     if (only_if_fallback && !st->fallback) {
+        if (seg > 0) {
+            long run = real_n0;
+            const int nseg = (n + seg - 1) / seg;
+            for (int f = 0; f + 1 < nseg && f < kMaxSeg; ++f) {
+                run += segcross[f];
+                if ((double)run > reset_at) { st->cadence_miss += 1; break; }
+            }
+        }
         // the parallel insert settled: apply its batch totals (pops, pushes, clock ticks, crossings, rounds)
         st->fifo_head = (uint32_t)(((unsigned long long)st->fifo_head + par_totals[0]) % cap);
         st->fifo_len = st->fifo_len + par_totals[1] - par_totals[0];
@@ -165,7 +182,10 @@ __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket 
         st->real_n += (int32_t)par_totals[3];
         st->pad[1] += (int32_t)par_totals[4];
         if ((int32_t)par_totals[4] > st->pad[2]) st->pad[2] = (int32_t)par_totals[4];
-        *host_mirror = *st;             // pinned host memory: the host reads it lagging, without a copy or a sync
+        host_mirror->st = *st;          // pinned host memory: the host reads it lagging, without a copy or a sync
+        host_mirror->n = (uint32_t)n; host_mirror->cross = par_totals[3];
+        __threadfence_system();
+        host_mirror->seq = seq;
         return;
     }
     if (only_if_fallback) st->pad[0] += 1;          // cumulative: batches handed to the in-order kernel
@@ -174,7 +194,9 @@ __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket 
     ctx.num = st->num; ctx.real_n = st->real_n; ctx.clk = st->clk;
     const float thr = st->thr;
     const uint32_t gflip = (uint32_t)st->flip;
+    int missed = 0;
     for (int i = 0; i < n; ++i) {
+        if (seg > 0 && i > 0 && i % seg == 0 && (double)ctx.real_n > reset_at) missed = 1;
         uint32_t x = (uint32_t)ids[i];
         float c = scores ? scores[i] : 1.0f;
         int k = hash_main(x, n1);
@@ -210,14 +232,19 @@ __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket 
     }
     st->fifo_head = ctx.head; st->fifo_len = ctx.len;
     st->num = ctx.num; st->real_n = ctx.real_n; st->clk = ctx.clk;
-    *host_mirror = *st;
+    st->cadence_miss += missed;
+    host_mirror->st = *st;
+    host_mirror->n = (uint32_t)n; host_mirror->cross = (uint32_t)(ctx.real_n - real_n0);
+    __threadfence_system();
+    host_mirror->seq = seq;
 }
 
 int cafe::launch_serial_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
-                               int only_if_fallback, hipStream_t st, const uint32_t *par_totals) {
+                               int only_if_fallback, hipStream_t st, const uint32_t *par_totals, const uint32_t *segcross) {
+    const double reset_at = s->adjust ? s->lim * 1.2 : 1e300;
     hipLaunchKernelGGL(k_insert_serial, dim3(1), dim3(64), 0, st, s->d_main, s->d_lru, s->d_fifo, s->fifo_cap,
                        s->d_state, s->n1, s->n2, d_ids, d_scores, n, d_ins, only_if_fallback, par_totals,
-                       reinterpret_cast<DevState *>(s->d_pinned));
+                       reinterpret_cast<Mirror *>(s->d_pinned), s->call_seq, reset_at, s->seg_len, segcross);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -409,6 +436,7 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     hipLaunchKernelGGL(k_fill_fifo, dim3((lim + 255) / 256), dim3(256), 0, 0, s->d_fifo, lim);
     hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, 0, s->d_state, (float)threshold, lim);
     CAFE_HIP_CHECK(hipDeviceSynchronize());
+    CAFE_HIP_CHECK(hipDeviceSynchronize());      // tables and scalars are in place whatever stream touches them first
     *out = s;
     return 0;
 }
@@ -435,6 +463,9 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
     else if (!strcmp(name, "max_rounds")) s->opt_max_rounds = value < 1 ? 1 : value;
     else if (!strcmp(name, "target_items")) s->opt_target_items = value < 16 ? 16 : value;
     else if (!strcmp(name, "hot_bypass")) s->opt_hot_bypass = value ? 1 : 0;
+    else if (!strcmp(name, "exact_reset")) s->opt_exact_reset = value ? 1 : 0;
+    else if (!strcmp(name, "overlap")) s->opt_overlap = value;
+    else if (!strcmp(name, "fuse_fields")) s->opt_fuse_fields = value ? 1 : 0;
     else { set_error("unknown option %s", name); return 1; }
     return 0;
 }
@@ -449,6 +480,8 @@ extern "C" int cafe_sketch_counters(cafe_sketch_t *s, int64_t *out8) {
     out8[1] -= h.pad[0];
     out8[3] = h.pad[1];
     out8[5] = h.pad[2];
+    out8[6] = h.cadence_miss;
+    if (h.bad_commit) { set_error("internal: the commit kernel refused %d staged entries", h.bad_commit); return 1; }
     return 0;
 }
 
@@ -537,8 +570,8 @@ extern "C" int cafe_sketch_import(cafe_sketch_t *s, const int32_t *mval, const f
     CAFE_HIP_CHECK(hipMemcpy(s->d_fifo, hf.data(), 4 * hf.size(), hipMemcpyHostToDevice));
     CAFE_HIP_CHECK(hipMemcpy(s->d_state, &h, sizeof(h), hipMemcpyHostToDevice));
     s->flip = ints6[3]; s->batch_num = ints6[4]; s->decay = decay;
-    s->real_n_ub = h.real_n;
-    s->real_n_pending = false;
+    s->base_real_n = h.real_n;
+    s->base_seq = s->call_seq;
     return 0;
 }
 
@@ -665,6 +698,66 @@ extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const flo
     return insert_dev_on(s, d_ids, d_scores, n, d_ins, (hipStream_t)stream, (hipStream_t)stream);
 }
 
+// ---- real_n as the host knows it ------------------------------------------------------------------
+// sketch.cpp:291 needs real_n at the start of every call.  The value lives on the device; the kernel that closes an
+// insert leaves a tagged snapshot in pinned memory, which the host reads lagging.  Bound = newest snapshot + an
+// estimate of the growth of the calls issued since: crossings per inserted id, 8 x the largest rate of the last 32
+// snapshots seen, + 64 (every id counts until 32 snapshots have been seen; option "exact_reset" keeps it that way).
+// Only when the bound passes 1.2 lim does the host wait for the exact value.  The closing kernel checks every
+// boundary against the real value and counts the ones the host got wrong (DevState::cadence_miss, counter [6]).
+static void read_mirror(cafe_sketch *s, Mirror *out) {
+    const volatile uint32_t *src = reinterpret_cast<const volatile uint32_t *>(s->h_pinned);
+    uint32_t a[sizeof(Mirror) / 4], b[sizeof(Mirror) / 4];
+    for (int tries = 0; tries < 16; ++tries) {
+        for (size_t i = 0; i < sizeof(Mirror) / 4; ++i) a[i] = src[i];
+        for (size_t i = 0; i < sizeof(Mirror) / 4; ++i) b[i] = src[i];
+        if (!memcmp(a, b, sizeof(a))) break;
+    }
+    memcpy(out, b, sizeof(Mirror));
+}
+
+long long cafe::growth_estimate(const cafe_sketch *s, long long n) {
+    if (s->opt_exact_reset) return n;
+    double rate = 0.0;
+    for (double r : s->rates) rate = std::max(rate, r);
+    const long long e = (long long)(8.0 * rate * (double)n) + 64;
+    return std::min(n, e);
+}
+
+long long cafe::real_n_bound(cafe_sketch *s) {
+    Mirror m;
+    read_mirror(s, &m);
+    long long ub = s->base_real_n;
+    uint32_t from = s->base_seq;
+    if ((int32_t)(m.seq - s->base_seq) > 0 && (int32_t)(s->call_seq - m.seq) >= 0) {      // newer than the base
+        ub = m.st.real_n;
+        from = m.seq;
+        if (m.seq != s->rate_seen_seq && m.n > 0) {
+            s->rates[s->rate_pos++ & 31] = (double)m.cross / (double)m.n;
+            s->rate_seen_seq = m.seq;
+        }
+    }
+    if (s->call_seq - from > 64u) return (long long)1 << 60;        // issued calls no longer in the ring
+    for (uint32_t q = from + 1; (int32_t)(s->call_seq - q) >= 0; ++q) ub += growth_estimate(s, s->issued[q & 63].n);
+    return ub;
+}
+
+// the exact value: waits for the last insert's snapshot
+int cafe::real_n_exact(cafe_sketch *s, long long *out) {
+    if (s->call_seq != s->base_seq) {
+        CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));
+        Mirror m;
+        read_mirror(s, &m);
+        if (m.seq != s->call_seq) { set_error("internal: state snapshot %u does not belong to call %u", m.seq, s->call_seq); return 1; }
+        if (m.n > 0 && m.seq != s->rate_seen_seq) { s->rates[s->rate_pos++ & 31] = (double)m.cross / (double)m.n; s->rate_seen_seq = m.seq; }
+        s->base_real_n = m.st.real_n;
+        s->base_seq = s->call_seq;
+        s->counters[7]++;
+    }
+    *out = s->base_real_n;
+    return 0;
+}
+
 int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st,
                         hipStream_t pre) {
     if (n < 0) { set_error("cafe_insert_dev: negative length"); return 1; }
@@ -673,6 +766,10 @@ int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_sco
     s->decay *= s->alpha;
     int flip_now = 0;
     if (s->decay > kDecayV) { s->decay /= kDecayV; s->flip ^= 1; flip_now = 1; }
+    // a call that stands for several reference calls (one per seg_len ids): the caller made sure that no flip and no
+    // reset falls on an inner boundary, so the remaining calls only advance the counters
+    if (s->seg_len > 0 && n > 0)
+        for (int k = 1; k < (n + s->seg_len - 1) / s->seg_len; ++k) { s->batch_num++; s->decay *= s->alpha; }
     const bool parallel = !s->opt_serial && n > 0;
     uint32_t *zero = nullptr;
     int zero_words = 0;
@@ -683,21 +780,20 @@ int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_sco
         pre = st;
     }
     hipLaunchKernelGGL(k_prologue, dim3(1), dim3(1024), 0, pre, s->d_state, flip_now, s->flip, zero, zero_words);
-    // sketch.cpp:291.  real_n after the previous insert was copied to pinned memory behind that insert; waiting
-    // for that copy (normally long done: later kernels of the step were queued behind it) gives the exact value.
-    if (s->adjust && (double)s->real_n_ub > s->lim * 1.2) {
-        if (s->real_n_pending) {
-            CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));        // rare: only when a reset may be due
-            s->real_n_pending = false;
-            s->real_n_ub = reinterpret_cast<const volatile DevState *>(s->h_pinned)->real_n;
-        }
-        if ((double)s->real_n_ub > s->lim * 1.2) {
+    // sketch.cpp:291
+    if (s->adjust && (double)real_n_bound(s) > s->lim * 1.2) {
+        long long exact;
+        if (real_n_exact(s, &exact)) return 1;          // rare: only when a reset may be due
+        if ((double)exact > s->lim * 1.2) {
             if (run_reset(s, pre)) return 1;
-            s->real_n_ub = s->lim;
+            s->base_real_n = s->lim;                     // sketch.cpp:113
+            s->base_seq = s->call_seq;
         }
     }
     s->counters[0]++;
     if (n == 0) return 0;
+    s->call_seq++;
+    s->issued[s->call_seq & 63] = {s->call_seq, n};
     int rc;
     if (s->opt_serial) {
         rc = launch_serial_insert(s, d_ids, d_scores, n, d_ins, 0, st);
@@ -705,11 +801,7 @@ int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_sco
     } else {
         rc = par_insert(s, d_ids, d_scores, n, d_ins, st, pre);
     }
-    s->real_n_ub += n;        // upper bound until the readback below is consumed
-    if (rc == 0) {
-        s->last_stream = st;            // the closing kernel mirrors the device state into pinned host memory
-        s->real_n_pending = true;
-    }
+    if (rc == 0) s->last_stream = st;       // the closing kernel mirrors the device state into pinned host memory
     return rc;
 }
 

@@ -100,7 +100,8 @@ class HotSketch:
     def counters(self):
         out = (ctypes.c_int64 * 8)()
         self.L.cafe_sketch_counters(self.h, out)
-        names = ("insert_calls", "parallel_calls", "inorder_calls", "rounds_total", "resets", "rounds_max")
+        names = ("insert_calls", "parallel_calls", "inorder_calls", "rounds_total", "resets", "rounds_max", "cadence_miss",
+                 "exact_waits")
         return dict(zip(names, (int(x) for x in out)))
 
     # -- the three reference operations ---------------------------------------------------------

@@ -90,11 +90,18 @@ int cafe_sketch_load(cafe_sketch_t *s, const char *path);
 /* Rebuild the free list from the tables (see `update` above). */
 int cafe_sketch_rebuild_free_list(cafe_sketch_t *s, cafe_stream_t stream);
 
-/* Options: "serial_insert" (1 = always use the one-lane in-order kernel), "max_rounds" (fix-point
- * rounds of the parallel insert before it gives the batch to the in-order kernel). */
+/* Options: "serial_insert" (1 = always use the one-lane in-order kernel), "max_rounds" (fix-point rounds of the
+ * parallel insert before it gives the batch to the in-order kernel), "target_items" (ids per bucket-owner
+ * workgroup), "hot_bypass" (0 = ids that are already hot go through the owner rounds too), "overlap" (bit 0: the
+ * score-independent head of an insert, bit 1: the backward's partition passes run on the handle's second stream;
+ * 0 = one stream), "exact_reset" (1 = the host's bound on real_n counts every issued id as a possible threshold
+ * crossing: waits for the device more often, never estimates), "fuse_fields" (0 = cafe_backward_update_dev with
+ * per_field always issues field by field). */
 int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int value);
 /* Counters since creation: [0] insert calls, [1] calls finished by the parallel path, [2] calls given
- * to the in-order kernel, [3] fix-point rounds used in total, [4] resets, [5] largest round count. */
+ * to the in-order kernel, [3] fix-point rounds used in total, [4] resets, [5] largest round count, [6] call
+ * boundaries at which the reference would have reset but the host's estimate of real_n said no (expected 0; the
+ * reset then happens at the next boundary), [7] times the host waited for the exact real_n. */
 int cafe_sketch_counters(cafe_sketch_t *s, int64_t *out8);
 
 /* sketch.cpp:260-265 batch_query: d_que[i] = -slot if d_ids[i] holds a hot slot, else d_ids[i]. */
@@ -148,11 +155,18 @@ int cafe_migrate_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_
 int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_que, const float *d_grad_out,
                           int batch, float lr, cafe_stream_t stream);
 
-/* The four calls above in the reference's order (scores, ONE batch_insert_val over all fields' ids in field-major
- * order, migration, backward + SGD) behind one host call; d_scores / d_ins [num_fields*batch] are outputs. */
+/* The four calls above in the reference's order (scores, batch_insert_val, migration, backward + SGD) behind one
+ * host call; d_scores / d_ins [num_fields*batch] are outputs.
+ * per_field != 0: the sketch sees what the reference's loop over fields gives it (dlrm_s_pytorch.py:734-738): one
+ *   batch_insert_val per field, i.e. decay and batch counter advance once per field and the reset test of
+ *   sketch.cpp:291 applies at every field boundary.  When no flip and no reset can fall on an inner boundary the
+ *   fields still run as ONE parallel insert (identical state and ins[], since the calls walk consecutive parts of
+ *   the same id stream); otherwise the step is issued field by field.  Migration is then evaluated once, after
+ *   the last field, which differs from field-by-field migration only while Threshold <= 1.
+ * per_field == 0: ONE batch_insert_val over all fields' ids in field-major order. */
 int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
                              const int32_t *d_que, const float *d_grad_out, int batch, float lr, float *d_scores,
-                             int32_t *d_ins, cafe_stream_t stream);
+                             int32_t *d_ins, int per_field, cafe_stream_t stream);
 
 /* ---- the same four steps for lookups in arbitrary order (each with its own field index), which is what
  *      a shard owner receives from its peers in the multi-GPU path (no reference

@@ -20,7 +20,7 @@ def _close(a, b, what):
 from cpu_pipeline import CpuPipeline as _CpuPipeline  # noqa: E402
 
 
-@pytest.mark.parametrize("dim,per_field", [(16, True), (128, True), (16, False), (128, False), (40, False)])
+@pytest.mark.parametrize("dim,per_field", [(16, True), (128, True), (16, "loop"), (16, False), (128, False), (40, False)])
 def test_collection_steps_match_oracle(dim, per_field, oracle_mod):
     from cafe_amd.collection import CafeEmbeddingCollection
     counts = [3000, 40, 50000, 7, 900]
@@ -59,3 +59,51 @@ def test_collection_steps_match_oracle(dim, per_field, oracle_mod):
             _close(coll.weight_hash[f].cpu().numpy(), cpu.w_cold[f], f"step {step} cold table {f}")
     assert newly > 50                                   # migrations really happened
     assert not oracle_mod.states_equal(coll.sketch.state(), cpu.sk.state())
+    assert coll.sketch.counters()["cadence_miss"] == 0
+
+
+
+@pytest.mark.parametrize("alpha,steps", [(1.0000005, 420), (1.1, 150)])
+def test_one_insert_per_step_keeps_the_per_field_cadence(alpha, steps, oracle_mod):
+    """cafe_backward_update_dev(per_field=1) runs a step as ONE parallel insert whenever no flip and no reset can fall
+    between two fields, and field by field otherwise; either way the sketch must be what the reference's loop over
+    fields leaves (one batch_insert_val per field: decay, batch counter and the reset test per field).  Long enough
+    for several resets (alpha ~ 1) or for flips at every position inside a step (alpha = 1.1: a flip every ~97
+    calls).  Bit-exact: ins[], every slot, scalars, free list.  Tables are compared in the run without flips only:
+    after a flip Threshold <= 1 and migration is evaluated per step rather than per field (SURVEY Q3,
+    include/cafe_hip.h)."""
+    from cafe_amd.collection import CafeEmbeddingCollection
+    counts = [30000, 4000, 90000, 700]
+    hash_sizes = [97, 13, 301, 5]
+    hotn, thr, B, lr, dim = 2500, 3, 256, 0.05, 16
+    coll = CafeEmbeddingCollection(counts, dim, hotn, hash_sizes, threshold=thr, adjust_thres=1, alpha=alpha, seed=1)
+    cpu = _CpuPipeline(oracle_mod, coll, thr, 1, alpha)
+    rng = np.random.default_rng(21)
+    F = len(counts)
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    for step in range(steps):
+        # the head of the Zipf law drifts, so new ids keep crossing the threshold and resets keep coming
+        ids = np.stack([(rng.zipf(1.2, size=B) - 1 + step * 5) % c for c in counts]).astype(np.int64)
+        ids[0] = np.maximum(ids[0], 1)
+        coll.forward(torch.from_numpy(ids).cuda())
+        cpu.forward(ids)
+        grad = torch.randn(F, B, dim, device="cuda", generator=gen)
+        scores, ins = coll.backward_update(grad, lr, per_field_calls=True)
+        sc = scores.cpu().numpy().reshape(F, B)
+        ins_want = cpu.backward_update(ids, grad.cpu().numpy(), sc, lr, True)
+        assert np.array_equal(ins.cpu().numpy().reshape(F, B), ins_want), f"step {step}: ins differs"
+        if step % 50 == 49 or step == steps - 1:
+            bad = oracle_mod.states_equal(coll.sketch.state(), cpu.sk.state())
+            assert not bad, f"step {step}: {bad[:3]}"
+    c = coll.sketch.counters()
+    st = coll.sketch.state()
+    assert c["cadence_miss"] == 0
+    assert c["insert_calls"] < steps * F, "no step ran as one insert"
+    if alpha < 1.001:
+        assert st["resets"] >= 2, st["resets"]
+        assert c["insert_calls"] < steps * F * 0.8, c        # a good part of the steps were one insert
+        _close(coll.weight_high.cpu().numpy(), cpu.w_hot, "hot table")
+        for f in range(F):
+            _close(coll.weight_hash[f].cpu().numpy(), cpu.w_cold[f], f"cold table {f}")
+    else:
+        assert st["flip"] in (0, 1) and st["batch_num"] == steps * F
