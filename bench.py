@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (samples); default: the config's")
-    ap.add_argument("--preheat", type=int, default=40, help="untimed steps that populate the sketch before warmup")
+    ap.add_argument("--id-batches", type=int, default=64, help="distinct synthetic id batches the steps cycle through")
+    ap.add_argument("--preheat", type=int, default=1000, help="untimed steps that populate the sketch before warmup")
     ap.add_argument("--lr", type=float, default=0.1)
     ap.add_argument("--zipf-a", type=float, default=1.05, help="Zipf exponent of the id streams (<= 1: uniform ids; diagnostics)")
     ap.add_argument("--per-field-calls", action="store_true",
@@ -190,7 +191,7 @@ def main():
         eng = ShardedCafeEmbedding(wl.counts, D, wl.hotn, wl.hash_sizes, wl.offsets, threshold=wl.threshold,
                                    alpha=wl.alpha, seed=1)
 
-    nb = 8
+    nb = args.id_batches
     ids_host = wl.make_ids(123 + rank, steps=nb, a=args.zipf_a)
     ids_dev = [torch.from_numpy(ids_host[i]).cuda() for i in range(nb)]
     grad = torch.randn(F, B, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5 + rank))
