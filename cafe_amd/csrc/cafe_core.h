@@ -60,7 +60,9 @@ struct Mirror {
     uint32_t seq;       // sequence number of the insert call this snapshot closes
     uint32_t n;         // ids of that call
     uint32_t cross;     // threshold crossings (real_n growth) of that call
-    uint32_t pad;
+    uint32_t pops;      // free-list pops of that call
+    uint32_t rejected;  // 1: a call issued "to be verified" was not applied (tables and scalars untouched)
+    uint32_t pad[3];
 };
 
 __host__ __device__ inline int hash_main(uint32_t x, int n1) { return (int)((long long)x * kHashMul % n1); }

@@ -726,58 +726,96 @@ extern "C" int cafe_backward_sgd_gid_dev(cafe_tables_t *t, const int32_t *d_fiel
 // Without a flip or a reset on an inner boundary, F calls over consecutive parts of the id stream equal ONE in-order
 // pass over the whole stream, so the step still runs as one parallel insert; the host proves "no inner flip" from
 // its own counters and "no inner reset" from its bound on real_n (cafe_sketch.hip), the closing kernel re-checks
-// the boundaries against the real value (counter [6]).  A step that may hold an inner flip or reset is issued field
-// by field.  per_field == 0: one batch_insert_val for the whole step (decay and reset once per step).
+// the boundaries against the real value (counter [6]).  A step that may hold an inner flip or reset, or that runs
+// while Threshold <= 1 (migration then depends on the state after each field), is issued field by field.  per_field == 0: one batch_insert_val for the whole step (decay and reset once per step).
 extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
                                         const int32_t *d_que, const float *d_grad_out, int batch, float lr, float *d_scores,
                                         int32_t *d_ins, int per_field, cafe_stream_t stream) {
     const int F = t->num_fields;
     const int total = F * batch;
     hipStream_t st = (hipStream_t)stream;
-    bool fuse = true;
+    // fuse: the step is proven free of inner flips and resets and runs as one insert.  verify: it may hold a reset
+    // boundary (or a free list about to run dry); it still runs as one insert, but the device checks the boundaries
+    // BEFORE anything is committed and rejects the batch if one fires or if the batch cannot be settled in parallel;
+    // the host waits for the verdict and issues a rejected step again field by field.  Neither: field by field.
+    bool fuse = true, verify = false;
     if (per_field && F > 1 && batch > 0) {
-        fuse = F <= kMaxSeg && s->opt_fuse_fields && !s->opt_serial;
+        fuse = F <= kMaxSeg && s->opt_fuse_fields && !s->opt_serial && total <= (1 << 21) && cafe::threshold_known_above_one(s);
+        bool flip_inside = false, flip_first = false;
         double d = s->decay;
-        for (int f = 0; f < F && fuse; ++f) {           // sketch.cpp:284-289 for the F calls ahead
+        for (int f = 0; f < F; ++f) {                    // sketch.cpp:284-289 for the F calls ahead
             d *= s->alpha;
-            if (d > kDecayV) { d /= kDecayV; if (f > 0) fuse = false; }
+            if (d > kDecayV) { d /= kDecayV; (f > 0 ? flip_inside : flip_first) = true; }
         }
-        if (fuse && s->adjust) {
-            const double at = s->lim * 1.2;
-            long long start = cafe::real_n_bound(s);
-            if ((double)(start + cafe::growth_estimate(s, total)) > at) {
-                if (cafe::real_n_exact(s, &start)) return 1;
-                if ((double)start > at) start = s->lim;                  // the first field's call begins with a reset
-                fuse = !((double)(start + cafe::growth_estimate(s, total)) > at);
+        // a flip at the first field is this call's own; the step then runs under Threshold / V
+        if (flip_inside || (flip_first && !((float)((double)s->host_thr / kDecayV) > 1.0f))) fuse = false;
+        if (fuse) {
+            bool sure = true;
+            // A free list that may run dry inside the batch would send the whole batch to the in-order kernel
+            // (cafe_insert_par.hip); typical right after a reset, until the few slots it freed are handed out.
+            (void)cafe::real_n_bound(s);                 // consumes the newest snapshot
+            if (s->fifo_hint < 0 || (s->fifo_hint > 0 && s->fifo_hint < cafe::growth_estimate(s, total))) sure = false;
+            if (sure && s->adjust) {
+                const double at = s->lim * 1.2;
+                long long start = cafe::real_n_bound(s);
+                if ((double)(start + cafe::growth_estimate(s, total)) > at) {
+                    if (cafe::real_n_exact(s, &start)) return 1;
+                    if ((double)start > at) start = s->lim;              // the first field's call begins with a reset
+                    sure = !((double)(start + cafe::growth_estimate(s, total)) > at);
+                }
+            }
+            if (!sure) { fuse = false; verify = !flip_first && s->opt_verify; }
+        }
+    }
+    bool scores_done = false, plan_done = false;
+    hipStream_t side = st;
+    if (fuse || verify) {
+        // What does not depend on this step's gradients runs on the sketch's second stream, beside the score kernels
+        // and the owner rounds: the head of the insert (per-call scalars, partition counts: ids and pre-batch tables
+        // only) and the partition passes of the backward (routing of the forward only).  Everything that was queued on
+        // `stream` before this call (the previous step's commit and SGD, this step's forward) is ordered before them.
+        // (small steps are launch-bound: the cross-stream dependencies cost more than the overlap returns)
+        if (s->opt_overlap && s->side_stream && s->side_stream != st && total >= 32768) side = s->side_stream;
+        if (side != st) {
+            CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, st));
+            CAFE_HIP_CHECK(hipStreamWaitEvent(side, s->ev_head_fork, 0));
+        }
+        if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
+        scores_done = true;
+        const double decay0 = s->decay;
+        const int batch_num0 = s->batch_num;
+        s->seg_len = per_field && F > 1 ? batch : 0;
+        s->verify_mode = verify ? 1 : 0;
+        const int rc = cafe::insert_dev_on(s, d_gids, d_scores, total, d_ins, st, (s->opt_overlap & 1) ? side : st);
+        s->seg_len = 0;
+        s->verify_mode = 0;
+        if (rc) return 1;
+        if (side != st) {
+            if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 1)) return 1;
+            plan_done = true;
+        }
+        if (verify) {
+            bool rejected = false;
+            if (cafe::last_insert_rejected(s, &rejected)) return 1;
+            if (rejected) {             // nothing was applied on the device: take the call counters back as well
+                s->decay = decay0;
+                s->batch_num = batch_num0;
+                s->counters[0]--;
+                fuse = false;
+            } else {
+                fuse = true;
             }
         }
     }
-    if (!fuse) {
-        if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
+    if (fuse) {
+        if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, 0, t->num_fields, stream)) return 1;
+    } else {
+        if (!scores_done && cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
         for (int f = 0; f < F; ++f) {
             const size_t o = (size_t)f * batch;
             if (cafe_insert_dev(s, d_gids + o, d_scores + o, batch, d_ins + o, stream)) return 1;
             if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, f, 1, stream)) return 1;
         }
-        return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, st);
     }
-    // What does not depend on this step's gradients runs on the sketch's second stream, beside the score kernels and
-    // the owner rounds: the head of the insert (per-call scalars, partition counts: ids and pre-batch tables only)
-    // and the partition passes of the backward (routing of the forward only).  Everything that was queued on `stream`
-    // before this call (the previous step's commit and SGD, this step's forward) is ordered before them.
-    hipStream_t side = s->opt_overlap && s->side_stream && s->side_stream != st ? s->side_stream : st;
-    if (side != st) {
-        CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, st));
-        CAFE_HIP_CHECK(hipStreamWaitEvent(side, s->ev_head_fork, 0));
-    }
-    if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
-    const bool plan_first = (s->opt_overlap & 4) != 0;
-    if (plan_first && side != st && backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 1)) return 1;
-    s->seg_len = per_field && F > 1 ? batch : 0;
-    const int rc = cafe::insert_dev_on(s, d_gids, d_scores, total, d_ins, st, (s->opt_overlap & 1) ? side : st);
-    s->seg_len = 0;
-    if (rc) return 1;
-    if (!plan_first && side != st && backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 1)) return 1;
-    if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, 0, t->num_fields, stream)) return 1;
-    return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, side != st ? 2 : 3);
+    return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, plan_done ? side : st, plan_done ? 2 : 3);
 }

@@ -93,6 +93,8 @@ struct Geo {
     int hot;                    // 1: ids that sit hot in the main table before the batch bypass the owner rounds
     uint32_t gflip;             // flip bit of this call (known on the host)
     int seg;                    // > 0: ids per reference call when this call stands for several (cafe_backward_update_dev)
+    int verify;                 // 1: a batch that cannot be settled, or holds a reset boundary, is REJECTED (nothing is
+                                // applied, the host issues it again field by field) instead of going to the in-order kernel
     FastMod fm1, fm2;
 };
 constexpr size_t kCtlWords = (sizeof(Ctl) + 3) / 4;
@@ -1064,7 +1066,7 @@ __global__ void __launch_bounds__(kScanBlock) k_finish_flags(
 
 // per-item exclusive ranks in batch order.  Every workgroup sums the block totals in front of it; workgroup 0 also
 // forms the batch totals, checks the free-list assumption and decides whether the result may be committed.
-__global__ void __launch_bounds__(kScanBlock) k_finish_ranks(Geo g, int nblocks, DevState *st, Ctl *ctl,
+__global__ void __launch_bounds__(kScanBlock) k_finish_ranks(Geo g, int nblocks, double reset_at, DevState *st, Ctl *ctl,
                                                              const uint8_t *__restrict__ flags,
                                                              const uint32_t *__restrict__ blocksum, uint32_t *__restrict__ poprank,
                                                              uint32_t *__restrict__ pushrank, uint32_t *__restrict__ clkrank) {
@@ -1104,7 +1106,19 @@ __global__ void __launch_bounds__(kScanBlock) k_finish_ranks(Geo g, int nblocks,
             st->rounds = (int32_t)ctl->final_round;
             st->maxpart = (int32_t)ctl->maxpart;
             st->pad[3] = (int32_t)ctl->maxhot;
-            if (!ok) st->fallback = 1;
+            if (g.verify) {
+                // sketch.cpp:291 at the inner boundaries, with the crossings k_finish_flags counted per segment
+                bool inner_reset = false;
+                long run = st->real_n;
+                const int nseg = (g.n + g.seg - 1) / g.seg;
+                for (int f = 0; f + 1 < nseg; ++f) {
+                    run += ctl->segcross[f];
+                    if ((double)run > reset_at) inner_reset = true;
+                }
+                if (!ok || inner_reset) st->fallback = 2;
+            } else if (!ok) {
+                st->fallback = 1;
+            }
         }
         tot[0] = tot[1] = tot[2] = 0;                 // block 0 starts at rank 0
     }
@@ -1233,6 +1247,7 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     g.hot = s->opt_hot_bypass ? 1 : 0;
     g.gflip = (uint32_t)s->flip;
     g.seg = s->seg_len > 0 && (n + s->seg_len - 1) / s->seg_len <= kMaxSeg ? s->seg_len : 0;
+    g.verify = s->verify_mode && g.seg > 0 ? 1 : 0;
     if (w.zr.reserve(4 * (kCtlWords + PP + 3 * (size_t)g.P1) + 16) || w.off.reserve(4 * (PP + g.P1) + 32) || w.rank.reserve(8 * N) ||
         w.items.reserve(3 * sizeof(Rec) * N) || w.hkey.reserve(8 * N + 16) || w.hrun.reserve(4 * N + 16) || w.hfin.reserve(8 * N + 16) || w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * kCapEv) ||
         w.evres.reserve(sizeof(EvRes) * N) || w.miss.reserve(N) || w.outm.reserve(N) || w.outl.reserve(N) ||
@@ -1361,7 +1376,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     hipLaunchKernelGGL(k_finish_flags, dim3(nb), dim3(kScanBlock), 0, st, g, tag, s->d_state, ctl, w.miss.as<uint8_t>(),
                        w.outm.as<uint8_t>(), w.outl.as<uint8_t>(), w.evres.as<EvRes>(), d_ins, flags, pushval,
                        w.blocksum.as<uint32_t>());
-    hipLaunchKernelGGL(k_finish_ranks, dim3(nb), dim3(kScanBlock), 0, st, g, nb, s->d_state, ctl, flags,
+    hipLaunchKernelGGL(k_finish_ranks, dim3(nb), dim3(kScanBlock), 0, st, g, nb, s->adjust ? s->lim * 1.2 : 1e300, s->d_state, ctl, flags,
                        w.blocksum.as<uint32_t>(), poprank, pushrank, clkrank);
     const int cb = std::min(g.P1 + g.P2, 2048);
     hipLaunchKernelGGL(k_commit, dim3(cb), dim3(256), 0, st, g, s->d_main, s->d_lru, s->d_fifo, s->fifo_cap, s->d_state, ctl,

@@ -75,11 +75,17 @@ struct cafe_sketch {
     double rates[32] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
     int rate_pos = 0;                   // crossings per inserted id of the last 32 snapshots seen (1 = not seen yet)
     uint32_t rate_seen_seq = 0;
-    int opt_fuse_fields = 1;
+    int opt_fuse_fields = 1, opt_verify = 1;
     int opt_exact_reset = 0;            // 1: count every issued id as a possible crossing (waits more often, never guesses)
     struct Issued { uint32_t seq; int n; };
     Issued issued[64];                  // ring of the most recent calls
+    int verify_mode = 0;                // with seg_len: see Geo::verify
     int seg_len = 0;                    // > 0: the call being issued stands for one reference call per seg_len ids
+    // Threshold as the host knows it: it changes at flips (host-driven) and resets (computed on the device: unknown
+    // until a snapshot of call thr_dirty_seq or later has been read)
+    long long fifo_hint = -1;           // free-list length of the newest snapshot (-1: unknown, a reset came later)
+    float host_thr = 0.f;
+    uint32_t thr_dirty_seq = 0;         // 0 = host_thr is current
 };
 
 struct cafe_tables {
@@ -113,7 +119,9 @@ int launch_serial_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_sc
 // depends on (the previous insert, the ids) and may have queued the score kernels on `st` behind that point
 long long growth_estimate(const cafe_sketch *s, long long n);
 long long real_n_bound(cafe_sketch *s);
+bool threshold_known_above_one(cafe_sketch *s);
 int real_n_exact(cafe_sketch *s, long long *out);
+int last_insert_rejected(cafe_sketch *s, bool *rejected);
 int insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st,
                   hipStream_t pre);
 }  // namespace cafe

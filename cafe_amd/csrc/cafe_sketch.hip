@@ -159,13 +159,25 @@ __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket 
                                                       const float *__restrict__ scores, int n, int32_t *__restrict__ ins,
                                                       int only_if_fallback, const uint32_t *par_totals, Mirror *host_mirror,
                                                       uint32_t seq, double reset_at, int seg, const uint32_t *segcross) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    const bool settled = only_if_fallback && !st->fallback;       // uniform
+    if (settled && lane != 0) return;
     // sketch.cpp:291 is evaluated by the host from a bound on real_n (cafe_insert_dev).  Checked here against the real
     // value: a call that should have begun with a reset, or -- for a call that stands for one call per `seg` ids --
     // an inner boundary at which the per-field call would have, is counted, never silently accepted.
-    const int32_t real_n0 = st->real_n;
-    if ((double)real_n0 > reset_at) st->cadence_miss += 1;
-    if (only_if_fallback && !st->fallback) {
+    const int32_t real_n0 = st->real_n, num0 = st->num;
+    if (only_if_fallback && st->fallback == 2) {          // rejected by k_finish_ranks: nothing was applied
+        if (lane == 0) {
+            host_mirror->st = *st;
+            host_mirror->n = (uint32_t)n; host_mirror->cross = 0; host_mirror->pops = 0; host_mirror->rejected = 1;
+            __threadfence_system();
+            host_mirror->seq = seq;
+        }
+        return;
+    }
+    if (lane == 0 && (double)real_n0 > reset_at) st->cadence_miss += 1;
+    if (settled) {
         if (seg > 0) {
             long run = real_n0;
             const int nseg = (n + seg - 1) / seg;
@@ -183,19 +195,24 @@ __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket 
         st->pad[1] += (int32_t)par_totals[4];
         if ((int32_t)par_totals[4] > st->pad[2]) st->pad[2] = (int32_t)par_totals[4];
         host_mirror->st = *st;          // pinned host memory: the host reads it lagging, without a copy or a sync
-        host_mirror->n = (uint32_t)n; host_mirror->cross = par_totals[3];
+        host_mirror->n = (uint32_t)n; host_mirror->cross = par_totals[3]; host_mirror->pops = par_totals[0];
+        host_mirror->rejected = 0;
         __threadfence_system();
         host_mirror->seq = seq;
         return;
     }
-    if (only_if_fallback) st->pad[0] += 1;          // cumulative: batches handed to the in-order kernel
+    if (only_if_fallback && lane == 0) st->pad[0] += 1;          // cumulative: batches handed to the in-order kernel
+    // One lane walks the batch.  (Measured: letting the other lanes pull the buckets of the next 64 ids into the cache
+    // does not shorten the walk -- 1.4 us per id either way: the two dependent loads per id cost an L2 round trip each.)
     SerialCtx ctx;
     ctx.fifo = fifo; ctx.cap = cap; ctx.head = st->fifo_head; ctx.len = st->fifo_len;
     ctx.num = st->num; ctx.real_n = st->real_n; ctx.clk = st->clk;
     const float thr = st->thr;
     const uint32_t gflip = (uint32_t)st->flip;
     int missed = 0;
-    for (int i = 0; i < n; ++i) {
+    if (lane != 0) return;
+    {
+      for (int i = 0; i < n; ++i) {
         if (seg > 0 && i > 0 && i % seg == 0 && (double)ctx.real_n > reset_at) missed = 1;
         uint32_t x = (uint32_t)ids[i];
         float c = scores ? scores[i] : 1.0f;
@@ -229,12 +246,15 @@ __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket 
         if (f < 0) got = lru_place(l, -f - 1, x, c, thr, ctx);
         store_lru(&lt[k2], l);
         ins[i] = got;
+      }
     }
     st->fifo_head = ctx.head; st->fifo_len = ctx.len;
     st->num = ctx.num; st->real_n = ctx.real_n; st->clk = ctx.clk;
     st->cadence_miss += missed;
     host_mirror->st = *st;
     host_mirror->n = (uint32_t)n; host_mirror->cross = (uint32_t)(ctx.real_n - real_n0);
+    host_mirror->pops = (uint32_t)(ctx.num - num0);
+    host_mirror->rejected = 0;
     __threadfence_system();
     host_mirror->seq = seq;
 }
@@ -409,6 +429,8 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     cafe_sketch *s = new cafe_sketch();
     CAFE_HIP_CHECK(hipGetDevice(&s->device));
     s->lim = lim; s->adjust = adjust_thres; s->alpha = alpha; s->lru_first = lru_first ? 1 : 0;
+    s->host_thr = (float)threshold;
+    s->fifo_hint = lim - 1;
     if (const char *e = getenv("CAFE_TARGET_ITEMS")) s->opt_target_items = std::max(16, atoi(e));   // tuning aids
     if (const char *e = getenv("CAFE_HOT_BYPASS")) s->opt_hot_bypass = atoi(e) ? 1 : 0;
     s->n1 = (int)(lim * 0.9);           // sketch.cpp:51-52
@@ -466,6 +488,7 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
     else if (!strcmp(name, "exact_reset")) s->opt_exact_reset = value ? 1 : 0;
     else if (!strcmp(name, "overlap")) s->opt_overlap = value;
     else if (!strcmp(name, "fuse_fields")) s->opt_fuse_fields = value ? 1 : 0;
+    else if (!strcmp(name, "verify")) s->opt_verify = value ? 1 : 0;
     else { set_error("unknown option %s", name); return 1; }
     return 0;
 }
@@ -572,6 +595,9 @@ extern "C" int cafe_sketch_import(cafe_sketch_t *s, const int32_t *mval, const f
     s->flip = ints6[3]; s->batch_num = ints6[4]; s->decay = decay;
     s->base_real_n = h.real_n;
     s->base_seq = s->call_seq;
+    s->host_thr = thr;
+    s->thr_dirty_seq = 0;
+    s->fifo_hint = fifo_len;
     return 0;
 }
 
@@ -701,8 +727,8 @@ extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const flo
 // ---- real_n as the host knows it ------------------------------------------------------------------
 // sketch.cpp:291 needs real_n at the start of every call.  The value lives on the device; the kernel that closes an
 // insert leaves a tagged snapshot in pinned memory, which the host reads lagging.  Bound = newest snapshot + an
-// estimate of the growth of the calls issued since: crossings per inserted id, 8 x the largest rate of the last 32
-// snapshots seen, + 64 (every id counts until 32 snapshots have been seen; option "exact_reset" keeps it that way).
+// estimate of the growth of the calls issued since: crossings (or pops, whichever is larger) per inserted id, 8 x the
+// largest rate of the last 32 snapshots seen, + 64 (every id counts until 32 snapshots have been seen; option "exact_reset" keeps it that way).
 // Only when the bound passes 1.2 lim does the host wait for the exact value.  The closing kernel checks every
 // boundary against the real value and counts the ones the host got wrong (DevState::cadence_miss, counter [6]).
 static void read_mirror(cafe_sketch *s, Mirror *out) {
@@ -729,17 +755,29 @@ long long cafe::real_n_bound(cafe_sketch *s) {
     read_mirror(s, &m);
     long long ub = s->base_real_n;
     uint32_t from = s->base_seq;
+    if (s->thr_dirty_seq && m.seq != 0 && (int32_t)(m.seq - s->thr_dirty_seq) >= 0 && (int32_t)(s->call_seq - m.seq) >= 0) {
+        s->host_thr = m.st.thr;         // the snapshot is behind the reset (and every flip) that made it unknown
+        s->thr_dirty_seq = 0;
+    }
     if ((int32_t)(m.seq - s->base_seq) > 0 && (int32_t)(s->call_seq - m.seq) >= 0) {      // newer than the base
         ub = m.st.real_n;
         from = m.seq;
+        s->fifo_hint = m.st.fifo_len;
         if (m.seq != s->rate_seen_seq && m.n > 0) {
-            s->rates[s->rate_pos++ & 31] = (double)m.cross / (double)m.n;
+            s->rates[s->rate_pos++ & 31] = (double)std::max(m.cross, m.pops) / (double)m.n;
             s->rate_seen_seq = m.seq;
         }
     }
     if (s->call_seq - from > 64u) return (long long)1 << 60;        // issued calls no longer in the ring
     for (uint32_t q = from + 1; (int32_t)(s->call_seq - q) >= 0; ++q) ub += growth_estimate(s, s->issued[q & 63].n);
     return ub;
+}
+
+// with Threshold <= 1 an id can turn hot inside the LRU table, and whether an eviction of a later field moves
+// it into the main table decides a field-by-field migration; such steps are issued field by field.
+bool cafe::threshold_known_above_one(cafe_sketch *s) {
+    (void)real_n_bound(s);              // consumes the newest snapshot
+    return s->thr_dirty_seq == 0 && s->host_thr > 1.0f;
 }
 
 // the exact value: waits for the last insert's snapshot
@@ -749,12 +787,38 @@ int cafe::real_n_exact(cafe_sketch *s, long long *out) {
         Mirror m;
         read_mirror(s, &m);
         if (m.seq != s->call_seq) { set_error("internal: state snapshot %u does not belong to call %u", m.seq, s->call_seq); return 1; }
-        if (m.n > 0 && m.seq != s->rate_seen_seq) { s->rates[s->rate_pos++ & 31] = (double)m.cross / (double)m.n; s->rate_seen_seq = m.seq; }
+        if (s->thr_dirty_seq) { s->host_thr = m.st.thr; s->thr_dirty_seq = 0; }
+        if (m.n > 0 && m.seq != s->rate_seen_seq) {
+            s->rates[s->rate_pos++ & 31] = (double)std::max(m.cross, m.pops) / (double)m.n;
+            s->rate_seen_seq = m.seq;
+        }
+        s->fifo_hint = m.st.fifo_len;
         s->base_real_n = m.st.real_n;
         s->base_seq = s->call_seq;
         s->counters[7]++;
     }
     *out = s->base_real_n;
+    return 0;
+}
+
+// waits for the insert issued last and tells whether the device rejected it (verify mode)
+int cafe::last_insert_rejected(cafe_sketch *s, bool *rejected) {
+    CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));
+    Mirror m;
+    read_mirror(s, &m);
+    if (m.seq != s->call_seq) { set_error("internal: state snapshot %u does not belong to call %u", m.seq, s->call_seq); return 1; }
+    *rejected = m.rejected != 0;
+    // either way the snapshot holds the exact scalars behind every call issued so far (a rejected call changes none)
+    if (!*rejected && m.n > 0 && m.seq != s->rate_seen_seq) {
+        s->rates[s->rate_pos++ & 31] = (double)std::max(m.cross, m.pops) / (double)m.n;
+        s->rate_seen_seq = m.seq;
+    }
+    s->base_real_n = m.st.real_n;
+    s->base_seq = s->call_seq;
+    s->fifo_hint = m.st.fifo_len;
+    if (s->thr_dirty_seq) { s->host_thr = m.st.thr; s->thr_dirty_seq = 0; }
+    if (*rejected) s->counters[1]--;        // it was counted as a call finished by the parallel path
+    s->counters[7]++;
     return 0;
 }
 
@@ -766,6 +830,10 @@ int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_sco
     s->decay *= s->alpha;
     int flip_now = 0;
     if (s->decay > kDecayV) { s->decay /= kDecayV; s->flip ^= 1; flip_now = 1; }
+    if (flip_now) {                              // k_prologue: thr = (float)((double)thr / V)
+        if (s->thr_dirty_seq) s->thr_dirty_seq = s->call_seq + 1;
+        else s->host_thr = (float)((double)s->host_thr / kDecayV);
+    }
     // a call that stands for several reference calls (one per seg_len ids): the caller made sure that no flip and no
     // reset falls on an inner boundary, so the remaining calls only advance the counters
     if (s->seg_len > 0 && n > 0)
@@ -788,6 +856,8 @@ int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_sco
             if (run_reset(s, pre)) return 1;
             s->base_real_n = s->lim;                     // sketch.cpp:113
             s->base_seq = s->call_seq;
+            s->thr_dirty_seq = s->call_seq + 1;          // sketch.cpp:112 rewrites Threshold on the device
+            s->fifo_hint = -1;                           // ... and hands slots back and out
         }
     }
     s->counters[0]++;

@@ -161,8 +161,9 @@ int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, const int32_t
  *   batch_insert_val per field, i.e. decay and batch counter advance once per field and the reset test of
  *   sketch.cpp:291 applies at every field boundary.  When no flip and no reset can fall on an inner boundary the
  *   fields still run as ONE parallel insert (identical state and ins[], since the calls walk consecutive parts of
- *   the same id stream); otherwise the step is issued field by field.  Migration is then evaluated once, after
- *   the last field, which differs from field-by-field migration only while Threshold <= 1.
+ *   the same id stream); otherwise the step is issued field by field.  The one-insert form evaluates migration
+ *   once, after the last field; that equals field-by-field migration as long as Threshold > 1, and steps that
+ *   run while Threshold <= 1 are issued field by field.
  * per_field == 0: ONE batch_insert_val over all fields' ids in field-major order. */
 int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
                              const int32_t *d_que, const float *d_grad_out, int batch, float lr, float *d_scores,

@@ -63,20 +63,22 @@ def test_collection_steps_match_oracle(dim, per_field, oracle_mod):
 
 
 
-@pytest.mark.parametrize("alpha,steps", [(1.0000005, 420), (1.1, 150)])
-def test_one_insert_per_step_keeps_the_per_field_cadence(alpha, steps, oracle_mod):
+@pytest.mark.parametrize("alpha,steps,verify", [(1.0000005, 420, 1), (1.0000005, 420, 0), (1.1, 150, 1)])
+def test_one_insert_per_step_keeps_the_per_field_cadence(alpha, steps, verify, oracle_mod):
     """cafe_backward_update_dev(per_field=1) runs a step as ONE parallel insert whenever no flip and no reset can fall
     between two fields, and field by field otherwise; either way the sketch must be what the reference's loop over
     fields leaves (one batch_insert_val per field: decay, batch counter and the reset test per field).  Long enough
     for several resets (alpha ~ 1) or for flips at every position inside a step (alpha = 1.1: a flip every ~97
-    calls).  Bit-exact: ins[], every slot, scalars, free list.  Tables are compared in the run without flips only:
-    after a flip Threshold <= 1 and migration is evaluated per step rather than per field (SURVEY Q3,
-    include/cafe_hip.h)."""
+    calls; after the first one Threshold <= 1, the regime of SURVEY Q3, where steps are issued field by field).
+    verify = 1: steps that MAY hold a reset boundary still run as one insert that the device rejects, before
+    committing anything, when a boundary fires (the host then issues the step field by field); 0: such steps are
+    issued field by field from the start.  Bit-exact: ins[], every slot, scalars, free list; tables within 1e-5."""
     from cafe_amd.collection import CafeEmbeddingCollection
     counts = [30000, 4000, 90000, 700]
     hash_sizes = [97, 13, 301, 5]
     hotn, thr, B, lr, dim = 2500, 3, 256, 0.05, 16
     coll = CafeEmbeddingCollection(counts, dim, hotn, hash_sizes, threshold=thr, adjust_thres=1, alpha=alpha, seed=1)
+    coll.sketch.set_option("verify", verify)
     cpu = _CpuPipeline(oracle_mod, coll, thr, 1, alpha)
     rng = np.random.default_rng(21)
     F = len(counts)
@@ -101,9 +103,9 @@ def test_one_insert_per_step_keeps_the_per_field_cadence(alpha, steps, oracle_mo
     assert c["insert_calls"] < steps * F, "no step ran as one insert"
     if alpha < 1.001:
         assert st["resets"] >= 2, st["resets"]
-        assert c["insert_calls"] < steps * F * 0.8, c        # a good part of the steps were one insert
-        _close(coll.weight_high.cpu().numpy(), cpu.w_hot, "hot table")
-        for f in range(F):
-            _close(coll.weight_hash[f].cpu().numpy(), cpu.w_cold[f], f"cold table {f}")
+        assert c["insert_calls"] < steps * F * (0.3 if verify else 0.8), c       # how many steps were one insert
     else:
-        assert st["flip"] in (0, 1) and st["batch_num"] == steps * F
+        assert st["batch_num"] == steps * F and st["thr"] < 1.0
+    _close(coll.weight_high.cpu().numpy(), cpu.w_hot, "hot table")
+    for f in range(F):
+        _close(coll.weight_hash[f].cpu().numpy(), cpu.w_cold[f], f"cold table {f}")
