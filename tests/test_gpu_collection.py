@@ -109,3 +109,33 @@ def test_one_insert_per_step_keeps_the_per_field_cadence(alpha, steps, verify, o
     _close(coll.weight_high.cpu().numpy(), cpu.w_hot, "hot table")
     for f in range(F):
         _close(coll.weight_hash[f].cpu().numpy(), cpu.w_cold[f], f"cold table {f}")
+
+
+@pytest.mark.parametrize("F,B", [(1, 300), (70, 8), (3, 1), (64, 40)])
+def test_per_field_cadence_edge_shapes(F, B, oracle_mod):
+    """One field (nothing to fuse), more fields than the device keeps boundary counters for (64: issued field by
+    field), a batch of one, exactly 64 fields: same sketch and tables as the oracle's per-field calls."""
+    from cafe_amd.collection import CafeEmbeddingCollection
+    rng = np.random.default_rng(F * 1000 + B)
+    counts = [int(c) for c in rng.integers(50, 4000, size=F)]
+    hash_sizes = [max(1, c // 37) for c in counts]
+    hotn, thr, lr, dim = 600, 2, 0.1, 8
+    coll = CafeEmbeddingCollection(counts, dim, hotn, hash_sizes, threshold=thr, adjust_thres=1, alpha=1.0000005, seed=2)
+    cpu = _CpuPipeline(oracle_mod, coll, thr, 1, 1.0000005)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    for step in range(30):
+        ids = np.stack([(rng.zipf(1.3, size=B) - 1) % c for c in counts]).astype(np.int64)
+        ids[0] = np.maximum(ids[0], 1)
+        coll.forward(torch.from_numpy(ids).cuda())
+        cpu.forward(ids)
+        grad = torch.randn(F, B, dim, device="cuda", generator=gen)
+        scores, ins = coll.backward_update(grad, lr, per_field_calls=True)
+        sc = scores.cpu().numpy().reshape(F, B)
+        if B == 1:
+            assert np.all(sc == 1.0)                    # a field's only lookup: ||g|| * 1 / ||g||
+        ins_want = cpu.backward_update(ids, grad.cpu().numpy(), sc, lr, True)
+        assert np.array_equal(ins.cpu().numpy().reshape(F, B), ins_want), f"step {step}: ins differs"
+    bad = oracle_mod.states_equal(coll.sketch.state(), cpu.sk.state())
+    assert not bad, bad[:3]
+    assert coll.sketch.counters()["cadence_miss"] == 0
+    _close(coll.weight_high.cpu().numpy(), cpu.w_hot, "hot table")
