@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (samples); default: the config's")
+    ap.add_argument("--drift", type=int, default=0,
+                    help="robustness runs: after every pass over the id batches all local ids move by this much (mod the "
+                         "field size), so new ids keep crossing the threshold and the sketch keeps resetting")
     ap.add_argument("--id-batches", type=int, default=64, help="distinct synthetic id batches the steps cycle through")
     ap.add_argument("--preheat", type=int, default=1000, help="untimed steps that populate the sketch before warmup")
     ap.add_argument("--lr", type=float, default=0.1)
@@ -197,7 +200,13 @@ def main():
     grad = torch.randn(F, B, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5 + rank))
     out = torch.empty(F, B, D, device="cuda")
 
+    counts_dev = torch.tensor(wl.counts, device="cuda", dtype=torch.int64)[:, None]
+
     def step(i, timed_idx=None):
+        if args.drift and i and i % nb == 0:
+            for t in ids_dev:
+                t.add_(args.drift).remainder_(counts_dev)
+                t[0].clamp_(min=1)
         eng.forward(ids_dev[i % nb], out=out)
         eng.backward_update(grad, args.lr, per_field_calls=cadence)
 

@@ -50,7 +50,8 @@ struct DevState {
     int32_t cadence_miss;    // cumulative: call boundaries at which sketch.cpp:291 would have reset but the host had not
     int32_t pad[4];
     int32_t bad_commit;      // cumulative: staged entries the commit kernel refused (index out of range) -- always 0
-    int32_t pad2[3];
+    int32_t why[3];          // cumulative, batches given to the in-order kernel (or rejected): [0] a workspace limit,
+                             // [1] the rounds that were enqueued did not settle it, [2] the free list changed state
 };
 
 // What the kernel that closes an insert leaves in pinned host memory: the host reads it lagging, without a sync.

@@ -37,8 +37,8 @@ constexpr int kThreads = 256;
 constexpr int kCapSmall = 1024;   // items an owner of a normal partition sorts in LDS (several workgroups per CU)
 constexpr int kCapHot = 2048;    // ... of a hot-bypass partition (they hold the heavy ids)
 constexpr int kCapBig = 8192;     // ... of a partition that holds a heavy id (one workgroup per CU)
-constexpr int kCapEv = 256;       // moves one main partition can receive per round
-constexpr int kCapEvL = 256;      // moves one LRU partition can emit per round
+constexpr int kCapEv = 512;       // moves one main partition can receive per round
+constexpr int kCapEvL = 1024;     // moves one LRU partition can emit per round (an item emits at most one)
 
 constexpr int kMaxBins = 8192;    // partitions per table (LDS histogram of k_assign)
 constexpr int kAssignChunk = 2048;
@@ -93,6 +93,7 @@ struct Geo {
     int hot;                    // 1: ids that sit hot in the main table before the batch bypass the owner rounds
     uint32_t gflip;             // flip bit of this call (known on the host)
     int seg;                    // > 0: ids per reference call when this call stands for several (cafe_backward_update_dev)
+    int big, big_hot;           // 1: the big-partition variants of the owners / of the hot bypass are enqueued
     int verify;                 // 1: a batch that cannot be settled, or holds a reset boundary, is REJECTED (nothing is
                                 // applied, the host issues it again field by field) instead of going to the in-order kernel
     FastMod fm1, fm2;
@@ -245,7 +246,7 @@ __global__ void __launch_bounds__(1024) k_assign(Geo g, const MainBucket *__rest
 
 // block 0: offsets of the main partitions, block 1: of the LRU partitions
 __global__ void __launch_bounds__(1024) k_offsets(Geo g, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ cnth,
-                                                  uint32_t *__restrict__ off, Ctl *ctl, const DevState *st, int big, int big_hot) {
+                                                  uint32_t *__restrict__ off, Ctl *ctl, const DevState *st) {
     __shared__ uint32_t sh[1024];
     __shared__ uint32_t carry;
     // block 0: main partitions, 1: LRU partitions, 2: hot-bypass partitions (offsets behind the other two)
@@ -259,9 +260,6 @@ __global__ void __launch_bounds__(1024) k_offsets(Geo g, const uint32_t *__restr
         int i = base + threadIdx.x;
         uint32_t v = i < P ? c[i] : 0u;
         if (v > (uint32_t)kCapBig) over = 1;
-        // the big-partition owners are only enqueued when recent calls needed them: a partition that would have no
-        // owner sends the batch to the in-order kernel (a main partition also takes up to kCapEv moves)
-        if (blockIdx.x == 2 ? (!big_hot && v > (uint32_t)kCapHot) : (!big && v + (blockIdx.x == 0 ? kCapEv : 0) > (uint32_t)kCapSmall)) over = 1;
         if (v > vmax) vmax = v;
         sh[threadIdx.x] = v;
         __syncthreads();
@@ -350,7 +348,10 @@ __global__ void __launch_bounds__(kThreads) k_hot_chain(Geo g, const MainBucket 
     const uint32_t o0 = off[g.P1 + g.P2 + 2 + p], o1 = off[g.P1 + g.P2 + 3 + p];
     if (ctl->overflow) return;
     const int total = (int)(o1 - o0);
-    if (BIG ? (total <= kCapHot) : (total > kCapHot)) return;
+    if (BIG ? (total <= kCapHot) : (total > kCapHot)) {       // the other size class owns it
+        if (!BIG && !g.big_hot && tid == 0) ctl->overflow = 1;
+        return;
+    }
     if (total > CAP) { if (tid == 0) ctl->overflow = 1; return; }
     if (total == 0) return;
     if (tid == 0) n_heavy = 0;
@@ -510,7 +511,10 @@ __global__ void __launch_bounds__(kThreads) k_main_round(
     if (ne_raw > (uint32_t)kCapEv) { if (tid == 0) ctl->overflow = 1; return; }
     const int ne = (int)ne_raw;
     const int total = np + ne;
-    if (BIG ? (total <= kCapSmall) : (total > kCapSmall)) return;           // the other size class owns it
+    if (BIG ? (total <= kCapSmall) : (total > kCapSmall)) {                 // the other size class owns it
+        if (!BIG && !g.big && tid == 0) ctl->overflow = 1;
+        return;
+    }
     if (total > CAP) { if (tid == 0) ctl->overflow = 1; return; }
     // Same moves as the last round this partition ran with => same result: its staged buckets, per-item
     // outcomes and move outcomes stand.  Lists are compared as sets (arrival order is not deterministic).
@@ -860,7 +864,10 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
     if (!BIG) for (int p = q; p < g.P1; p += gridDim.x) if (tid == 0) evcnt[nxt * g.P1 + p] = 0;
 
     const int cnt = (int)(o1 - o0);
-    if (BIG ? (cnt <= kCapSmall) : (cnt > kCapSmall)) return;
+    if (BIG ? (cnt <= kCapSmall) : (cnt > kCapSmall)) {
+        if (!BIG && !g.big && tid == 0) ctl->overflow = 1;
+        return;
+    }
     if (cnt > CAP) { if (tid == 0) ctl->overflow = 1; return; }
     MoveEv *mine_ev = myev + (size_t)q * kCapEvL;
     const bool dirty = round == 1 || ldirty[par * g.P2 + q];
@@ -1097,9 +1104,11 @@ __global__ void __launch_bounds__(kScanBlock) k_finish_ranks(Geo g, int nblocks,
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
             bool ok = !(st->fallback || ctl->overflow) && ctl->final_round != 0;
+            if (!ok) st->why[ctl->overflow ? 0 : 1] += 1;
             if (ok) {
                 if (st->fifo_len > 0) ok = tot[0] <= (unsigned long long)st->fifo_len;      // never ran dry
                 else ok = tot[1] == 0;                                                       // never refilled
+                if (!ok) st->why[2] += 1;
             }
             ctl->totals[0] = (uint32_t)tot[0]; ctl->totals[1] = (uint32_t)tot[1]; ctl->totals[2] = (uint32_t)tot[2];
             ctl->totals[3] = (uint32_t)tot[3]; ctl->totals[4] = ctl->final_round;
@@ -1248,6 +1257,7 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     g.gflip = (uint32_t)s->flip;
     g.seg = s->seg_len > 0 && (n + s->seg_len - 1) / s->seg_len <= kMaxSeg ? s->seg_len : 0;
     g.verify = s->verify_mode && g.seg > 0 ? 1 : 0;
+    g.big = g.big_hot = 1;
     if (w.zr.reserve(4 * (kCtlWords + PP + 3 * (size_t)g.P1) + 16) || w.off.reserve(4 * (PP + g.P1) + 32) || w.rank.reserve(8 * N) ||
         w.items.reserve(3 * sizeof(Rec) * N) || w.hkey.reserve(8 * N + 16) || w.hrun.reserve(4 * N + 16) || w.hfin.reserve(8 * N + 16) || w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * kCapEv) ||
         w.evres.reserve(sizeof(EvRes) * N) || w.miss.reserve(N) || w.outm.reserve(N) || w.outl.reserve(N) ||
@@ -1284,18 +1294,32 @@ static void launch_plan(cafe_sketch *s, int n, int &rounds, bool &big, bool &big
     rounds = max_rounds;
     big = true;
     big_hot = true;
+    // A batch that left the parallel path (pad[0] counts them) means the guesses were too tight for what the data
+    // does now -- a popular id that is new, a shift of the distribution: stay generous for a while.
+    if (fb->pad[0] != s->seen_inorder) { s->seen_inorder = fb->pad[0]; s->generous_calls = 256; }
     if (s->last_seen_batch != n) {         // other batch size: forget what was learnt
         for (int &h : s->hint_rounds) h = 0;
+        for (int &h : s->hint_part) h = 0;
+        for (int &h : s->hint_hot) h = 0;
         s->last_seen_batch = n;
         return;
     }
-    if (fb->fallback || fb->rounds <= 0) { for (int &h : s->hint_rounds) h = 0; return; }
-    s->hint_rounds[s->hint_pos++ & 7] = fb->rounds;
-    int known = 0, most = 0;
+    if (fb->fallback || fb->rounds <= 0) {
+        for (int &h : s->hint_rounds) h = 0;
+        return;
+    }
+    s->hint_rounds[s->hint_pos & 7] = fb->rounds;
+    s->hint_part[s->hint_pos & 7] = fb->maxpart;
+    s->hint_hot[s->hint_pos & 7] = fb->pad[3];
+    s->hint_pos++;
+    int known = 0, most = 0, part = 0, hot = 0;
     for (int h : s->hint_rounds) { known += h > 0; most = std::max(most, h); }
+    for (int h : s->hint_part) part = std::max(part, h);
+    for (int h : s->hint_hot) hot = std::max(hot, h);
+    if (s->generous_calls > 0) { s->generous_calls--; return; }
     if (known >= 4) rounds = std::min(max_rounds, most + 2);
-    if (known >= 4 && fb->maxpart > 0 && (long)fb->maxpart * 3 / 2 + kCapEv <= kCapSmall) big = false;
-    if (known >= 4 && (long)fb->pad[3] * 3 / 2 <= kCapHot) big_hot = false;
+    if (known >= 4 && part > 0 && (long)part * 3 / 2 + 256 <= kCapSmall) big = false;
+    if (known >= 4 && (long)hot * 3 / 2 <= kCapHot) big_hot = false;
 }
 
 int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st,
@@ -1328,8 +1352,11 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     int rounds;
     bool big, big_hot;
     launch_plan(s, n, rounds, big, big_hot);
-    hipLaunchKernelGGL(k_offsets, dim3(g.hot ? 3 : 2), dim3(1024), 0, pre, g, cnt, cnth, off, ctl, s->d_state, big ? 1 : 0,
-                       big_hot ? 1 : 0);
+    // the big-partition owners are only enqueued when recent calls needed them; the normal owners flag a partition that
+    // is too large for them and has no other owner, which sends the batch to the in-order kernel
+    g.big = big ? 1 : 0;
+    g.big_hot = big_hot ? 1 : 0;
+    hipLaunchKernelGGL(k_offsets, dim3(g.hot ? 3 : 2), dim3(1024), 0, pre, g, cnt, cnth, off, ctl, s->d_state);
     if (pre != st) {         // the scores come in here
         CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, pre));
         CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));

@@ -65,7 +65,9 @@ struct cafe_sketch {
     int hot_on_side = 1, opt_overlap = 3;     // measured: 0.318 ms per cfg3 step against 0.330 with one stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_head_fork = nullptr, ev_head_join = nullptr;
     int hint_rounds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // final round counts of recent calls (0 = unknown)
+    int hint_part[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hint_hot[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // largest partitions of recent calls
     int hint_pos = 0;
+    int seen_inorder = 0, generous_calls = 0;   // launch_plan: full rounds and big-partition owners after a fallback
     long long last_seen_batch = -1;
     // real_n as the host knows it without a sync: the last snapshot of the pinned mirror plus a growth estimate for the
     // calls issued since (see real_n_bound in cafe_sketch.hip)

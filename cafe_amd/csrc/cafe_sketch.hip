@@ -495,6 +495,13 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
 
 static int read_state(cafe_sketch *s, DevState *h);
 
+extern "C" int cafe_sketch_fallback_reasons(cafe_sketch_t *s, int64_t *out3) {
+    DevState h;
+    if (read_state(s, &h)) return 1;
+    for (int i = 0; i < 3; ++i) out3[i] = h.why[i];
+    return 0;
+}
+
 extern "C" int cafe_sketch_counters(cafe_sketch_t *s, int64_t *out8) {
     DevState h;
     if (read_state(s, &h)) return 1;

@@ -102,7 +102,11 @@ class HotSketch:
         self.L.cafe_sketch_counters(self.h, out)
         names = ("insert_calls", "parallel_calls", "inorder_calls", "rounds_total", "resets", "rounds_max", "cadence_miss",
                  "exact_waits")
-        return dict(zip(names, (int(x) for x in out)))
+        d = dict(zip(names, (int(x) for x in out)))
+        why = (ctypes.c_int64 * 3)()
+        self.L.cafe_sketch_fallback_reasons(self.h, why)
+        d["left_parallel_path"] = {"workspace_limit": int(why[0]), "rounds_not_settled": int(why[1]), "free_list": int(why[2])}
+        return d
 
     # -- the three reference operations ---------------------------------------------------------
     def query(self, ids, out=None):

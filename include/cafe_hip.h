@@ -103,6 +103,10 @@ int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int value);
  * boundaries at which the reference would have reset but the host's estimate of real_n said no (expected 0; the
  * reset then happens at the next boundary), [7] times the host waited for the exact real_n. */
 int cafe_sketch_counters(cafe_sketch_t *s, int64_t *out8);
+/* Why batches left the parallel path (given to the in-order kernel, or rejected in verify mode), since creation:
+ * [0] a workspace limit (partition larger than an owner can sort, move list full, clock range), [1] the fix-point
+ * rounds that were enqueued did not settle the batch, [2] the free list ran dry or was refilled inside the batch. */
+int cafe_sketch_fallback_reasons(cafe_sketch_t *s, int64_t *out3);
 
 /* sketch.cpp:260-265 batch_query: d_que[i] = -slot if d_ids[i] holds a hot slot, else d_ids[i]. */
 int cafe_query_dev(cafe_sketch_t *s, const int32_t *d_ids, int n, int32_t *d_que, cafe_stream_t stream);
