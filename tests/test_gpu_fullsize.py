@@ -1,0 +1,72 @@
+"""The hot path at BASELINE.json's full single-GPU size (cfg3: 26 fields, 880 M ids, D = 128, batch 8192, a
+563 200-row sketch; 212 992 lookups per step) against the oracle fed the same stream with the reference's per-field
+calls: ins[] of every step and the complete sketch state bit-exact; forward rows exact copies; tables after the last
+steps within 1e-5 relative.  Threshold 20 instead of 500 so that 40 steps already hold thousands of hot ids, moves
+and migrations."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+from cpu_pipeline import CpuPipeline  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def _close(a, b, what):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert err <= RTOL, f"{what}: max rel err {err:.3e}"
+
+
+def test_cfg3_full_size_steps(oracle_mod):
+    from cafe_amd.collection import CafeEmbeddingCollection
+    from cafe_amd.config import workload
+    wl = workload("cfg3")
+    F, B, D, thr, lr = wl.num_fields, wl.batch, wl.dim, 20, 0.05
+    coll = CafeEmbeddingCollection(wl.counts, D, wl.hotn, wl.hash_sizes, wl.offsets, threshold=thr, alpha=wl.alpha, seed=4)
+    ora = oracle_mod.Oracle(wl.hotn, thr, 1, wl.alpha, 1)
+    steps, table_steps = 40, 2
+    ids_all = wl.make_ids(77, steps=steps)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    cpu = None
+    newly = 0
+    for step in range(steps):
+        ids = ids_all[step]
+        d_ids = torch.from_numpy(ids).cuda()
+        if step == steps - table_steps:          # from here on the tables are followed on the host as well
+            cpu = CpuPipeline(oracle_mod, coll, thr, 1, wl.alpha)
+            cpu.sk = ora
+        out = coll.forward(d_ids)
+        gids = (ids + wl.offsets[:, None]).astype(np.int64)
+        que = np.stack([ora.query(gids[f]) for f in range(F)])
+        assert np.array_equal(coll._buf["que"].cpu().numpy().reshape(F, B), que), f"step {step}: routing"
+        if cpu is not None:
+            _close(out.cpu().numpy(), cpu.forward(ids), f"step {step} forward")
+            # the gather itself is a pure copy: bit-exact against the GPU's own tables under the oracle's routing
+            gh = coll.weight_high.cpu().numpy()
+            got = out.cpu().numpy()
+            for f in range(F):
+                mine, _ = oracle_mod.ref_forward(que[f], gh, coll.weight_hash[f].cpu().numpy(), wl.hash_sizes[f])
+                assert np.array_equal(got[f], mine), f"step {step} field {f}: gathered rows are not exact copies"
+        grad = torch.randn(F, B, D, device="cuda", generator=gen)
+        scores, ins = coll.backward_update(grad, lr, per_field_calls=True)
+        sc = scores.cpu().numpy().reshape(F, B)
+        if cpu is not None:
+            ins_want = cpu.backward_update(ids, grad.cpu().numpy(), sc, lr, True)
+        else:
+            ins_want = np.stack([ora.insert_val(gids[f], sc[f]) for f in range(F)])
+        assert np.array_equal(ins.cpu().numpy().reshape(F, B), ins_want), f"step {step}: ins differs"
+        newly += int((ins_want != 0).sum())
+    bad = oracle_mod.states_equal(coll.sketch.state(), ora.state())
+    assert not bad, bad[:3]
+    c = coll.sketch.counters()
+    assert c["cadence_miss"] == 0 and c["insert_calls"] < steps * F / 2, c       # the steps ran as one insert each
+    assert newly > 2000, newly
+    _close(coll.weight_high.cpu().numpy(), cpu.w_hot, "hot table")
+    for f in range(F):
+        _close(coll.weight_hash[f].cpu().numpy(), cpu.w_cold[f], f"cold table {f}")
