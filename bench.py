@@ -279,8 +279,10 @@ def main():
             "data": "synthetic Zipf(1.05) ids, random-init tables, random upstream gradient",
             "config": {"workload": f"{wl.name}: {F} fields, {sum(wl.counts)} ids, D={D}, batch {B}/GPU, hotn {wl.hotn}, "
                                    f"compress {wl.compress_rate}, hash-rate {wl.hash_rate}, threshold {wl.threshold}",
-                       "sketch_calls": {True: "one per field (reference cadence), run as one insert per step",
-                                        "loop": "one per field, issued one by one", False: "one per step"}[cadence],
+                       "sketch_calls": ("one per step and shard (SURVEY 8e: a shard equals an independent sketch fed its "
+                                        "sub-stream)" if world > 1 else
+                                        {True: "one per field (reference cadence), run as one insert per step",
+                                         "loop": "one per field, issued one by one", False: "one per step"}[cadence]),
                        "parallelism": "single GPU" if world == 1 else f"id-hash sharded x{world}, RCCL all-to-all",
                        "preheat_steps": args.preheat},
             "sketch": eng.sketch.counters() if hasattr(eng, "sketch") else None,
