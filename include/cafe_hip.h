@@ -96,7 +96,8 @@ int cafe_sketch_rebuild_free_list(cafe_sketch_t *s, cafe_stream_t stream);
  * score-independent head of an insert, bit 1: the backward's partition passes run on the handle's second stream;
  * 0 = one stream), "exact_reset" (1 = the host's bound on real_n counts every issued id as a possible threshold
  * crossing: waits for the device more often, never estimates), "fuse_fields" (0 = cafe_backward_update_dev with
- * per_field always issues field by field). */
+ * per_field always issues field by field), "verify" (0 = a step that may hold a reset boundary is issued field by
+ * field from the start instead of as one insert the device checks before committing). */
 int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int value);
 /* Counters since creation: [0] insert calls, [1] calls finished by the parallel path, [2] calls given
  * to the in-order kernel, [3] fix-point rounds used in total, [4] resets, [5] largest round count, [6] call
