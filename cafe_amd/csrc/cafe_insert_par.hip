@@ -93,6 +93,7 @@ struct Geo {
     int hot;                    // 1: ids that sit hot in the main table before the batch bypass the owner rounds
     uint32_t gflip;             // flip bit of this call (known on the host)
     int seg;                    // > 0: ids per reference call when this call stands for several (cafe_backward_update_dev)
+    int last_round;             // rounds enqueued; the LRU half of the last one is not (see final_round_of)
     int big, big_hot;           // 1: the big-partition variants of the owners / of the hot bypass are enqueued
     int verify;                 // 1: a batch that cannot be settled, or holds a reset boundary, is REJECTED (nothing is
                                 // applied, the host issues it again field by field) instead of going to the in-order kernel
@@ -1023,6 +1024,14 @@ __global__ void __launch_bounds__(kThreads) k_lru_round(
 // ------------------------------------------------------------------------------------------------
 // finish: batch-ordered prefix sums, checks, commit
 // ------------------------------------------------------------------------------------------------
+// The round whose main half found the miss set unchanged is the answer.  LRU round r says so for rounds < last; for the
+// last enqueued round nobody has to run: its LRU half would either only say so or compute moves no main round consumes.
+__device__ inline uint32_t final_round_of(const Geo &g, const Ctl *ctl) {
+    uint32_t fr = ctl->final_round;
+    if (!fr && g.last_round > 0 && ctl->changed[g.last_round] == 0) fr = (uint32_t)g.last_round;
+    return fr;
+}
+
 // flags per item: bit0 pop, bit1 push, bit2 clock tick
 __global__ void __launch_bounds__(kScanBlock) k_finish_flags(
     Geo g, unsigned long long call_tag, const DevState *st, Ctl *ctl, const uint8_t *__restrict__ miss,
@@ -1031,7 +1040,7 @@ __global__ void __launch_bounds__(kScanBlock) k_finish_flags(
     __shared__ uint32_t s_pop, s_push, s_clk, s_cross;
     if (threadIdx.x == 0) { s_pop = s_push = s_clk = s_cross = 0; }
     __syncthreads();
-    const bool live = !(st->fallback || ctl->overflow) && ctl->final_round != 0;
+    const bool live = !(st->fallback || ctl->overflow) && final_round_of(g, ctl) != 0;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t pop = 0, push = 0, clk = 0, cross = 0;
     if (live && i < g.n) {
@@ -1103,6 +1112,7 @@ __global__ void __launch_bounds__(kScanBlock) k_finish_ranks(Geo g, int nblocks,
     for (int k = 0; k < kScanBlock / 64; ++k) { tot[0] += red[0][k]; tot[1] += red[1][k]; tot[2] += red[2][k]; tot[3] += red[3][k]; }
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
+            ctl->final_round = final_round_of(g, ctl);
             bool ok = !(st->fallback || ctl->overflow) && ctl->final_round != 0;
             if (!ok) st->why[ctl->overflow ? 0 : 1] += 1;
             if (ok) {
@@ -1258,6 +1268,7 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     g.seg = s->seg_len > 0 && (n + s->seg_len - 1) / s->seg_len <= kMaxSeg ? s->seg_len : 0;
     g.verify = s->verify_mode && g.seg > 0 ? 1 : 0;
     g.big = g.big_hot = 1;
+    g.last_round = 0;
     if (w.zr.reserve(4 * (kCtlWords + PP + 3 * (size_t)g.P1) + 16) || w.off.reserve(4 * (PP + g.P1) + 32) || w.rank.reserve(8 * N) ||
         w.items.reserve(3 * sizeof(Rec) * N) || w.hkey.reserve(8 * N + 16) || w.hrun.reserve(4 * N + 16) || w.hfin.reserve(8 * N + 16) || w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * kCapEv) ||
         w.evres.reserve(sizeof(EvRes) * N) || w.miss.reserve(N) || w.outm.reserve(N) || w.outl.reserve(N) ||
@@ -1308,6 +1319,7 @@ static void launch_plan(cafe_sketch *s, int n, int &rounds, bool &big, bool &big
         for (int &h : s->hint_rounds) h = 0;
         return;
     }
+    s->round_hist[std::min(std::max(fb->rounds, 0), 17)]++;
     s->hint_rounds[s->hint_pos & 7] = fb->rounds;
     s->hint_part[s->hint_pos & 7] = fb->maxpart;
     s->hint_hot[s->hint_pos & 7] = fb->pad[3];
@@ -1356,6 +1368,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
     // is too large for them and has no other owner, which sends the batch to the in-order kernel
     g.big = big ? 1 : 0;
     g.big_hot = big_hot ? 1 : 0;
+    g.last_round = rounds;
     hipLaunchKernelGGL(k_offsets, dim3(g.hot ? 3 : 2), dim3(1024), 0, pre, g, cnt, cnth, off, ctl, s->d_state);
     if (pre != st) {         // the scores come in here
         CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, pre));
@@ -1390,6 +1403,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int 
         if (r == 2 && g.hot && s->hot_on_side) CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_join, 0));
         CAFE_MAIN(kCapSmall, false);
         if (big) CAFE_MAIN(kCapBig, true);
+        if (r == rounds) break;            // final_round_of
         CAFE_LRU(kCapSmall, false);
         if (big) CAFE_LRU(kCapBig, true);
     }

@@ -67,6 +67,7 @@ struct cafe_sketch {
     int hint_rounds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // final round counts of recent calls (0 = unknown)
     int hint_part[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hint_hot[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // largest partitions of recent calls
     int hint_pos = 0;
+    long round_hist[18] = {0};          // final round of the calls seen through the snapshots (diagnostics)
     int seen_inorder = 0, generous_calls = 0;   // launch_plan: full rounds and big-partition owners after a fallback
     long long last_seen_batch = -1;
     // real_n as the host knows it without a sync: the last snapshot of the pinned mirror plus a growth estimate for the

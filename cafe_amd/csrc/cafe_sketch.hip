@@ -465,6 +465,11 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
 
 extern "C" int cafe_sketch_destroy(cafe_sketch_t *s) {
     if (!s) return 0;
+    if (getenv("CAFE_DEBUG_ROUNDS")) {
+        fprintf(stderr, "cafe: final rounds seen:");
+        for (int i = 0; i < 18; ++i) if (s->round_hist[i]) fprintf(stderr, " %d:%ld", i, s->round_hist[i]);
+        fprintf(stderr, "\n");
+    }
     (void)hipDeviceSynchronize();
     par_free(s);
     (void)hipFree(s->d_main); (void)hipFree(s->d_lru); (void)hipFree(s->d_fifo); (void)hipFree(s->d_state);
