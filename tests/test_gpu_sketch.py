@@ -172,3 +172,29 @@ def test_reference_abi_drop_in():
     """The g++-built sklib.so's entry points (sketch.cpp:300-327), bound the way the reference binds them."""
     r = subprocess.run([sys.executable, "-c", _ABI_CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=300)
     assert "ABI_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("option,value,reason", [("max_rounds", 1, "rounds_not_settled"), ("target_items", 16, None)])
+def test_batches_that_leave_the_parallel_path_stay_exact(option, value, reason, oracle_mod):
+    """Too few rounds enqueued to settle a batch (max_rounds = 1), or an unusual partition size: the batch goes to the
+    in-order kernel untouched (or runs with other partitions) -- never a different result -- and the reason is
+    counted (cafe_sketch_fallback_reasons)."""
+    from cafe_amd.sketch import HotSketch
+    lim, thr, batch, space = 1200, 4, 4096, 20000
+    ora = oracle_mod.Oracle(lim, thr, 1, 1.0000005, 1)
+    sk = HotSketch(lim, thr, 1, 1.0000005, 1)
+    sk.set_option(option, value)
+    rng = np.random.default_rng(5)
+    for c in range(14):
+        ids = ((rng.zipf(1.2, size=batch) - 1) % space + 1).astype(np.int64)
+        v = (rng.random(batch, dtype=np.float32) * np.float32(8.0)).astype(np.float32)
+        want = ora.insert_val(ids, v)
+        got = sk.insert_val(ids, v).cpu().numpy()
+        assert np.array_equal(got, want), f"call {c}: ins differs"
+    bad = oracle_mod.states_equal(sk.state(), ora.state())
+    assert not bad, bad[:3]
+    c = sk.counters()
+    assert c["cadence_miss"] == 0
+    if reason:
+        assert c["inorder_calls"] > 0 and c["left_parallel_path"][reason] > 0, c
+        assert c["inorder_calls"] == sum(c["left_parallel_path"].values()), c
