@@ -32,3 +32,18 @@ def test_no_oracle_in_product_package():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "cafe_oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/cafe_hip.h is the drop-in boundary: it must compile as C99 on its own (no C++ or torch types)."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        import pytest
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include "cafe_hip.h"\nint main(void) { return cafe_version() < 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(root, "include"), str(src)])
