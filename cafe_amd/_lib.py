@@ -52,6 +52,7 @@ SYMBOLS = {
     "cafe_forward_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "cafe_forward_ml_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cafe_scores_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "cafe_scores_noalloc_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "cafe_migrate_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "cafe_backward_sgd_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_float, _vp]),
     "cafe_backward_update_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_float, _vp, _vp,

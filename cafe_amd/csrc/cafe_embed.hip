@@ -12,6 +12,26 @@
 using namespace cafe;
 
 // ------------------------------------------------------------------------------------------------
+// Scratch of cafe_scores_noalloc_dev: the per-lookup gradient norms that cafe_scores_dev keeps in a workspace it
+// allocates.  One copy per GPU, held until the process ends (4 MiB).  `g_noalloc_scratch` is a host-side stand-in for
+// the symbol, never a device address: host code uses the per-device pointer hipGetSymbolAddress returned.
+// ------------------------------------------------------------------------------------------------
+constexpr int kNoAllocMaxLookups = 1 << 20;
+constexpr int kNoAllocMaxDevices = 64;
+static __device__ __align__(256) float g_noalloc_scratch[kNoAllocMaxLookups];
+static float *g_noalloc_ptr[kNoAllocMaxDevices];      // [device] -> address of that device's copy, nullptr = not looked up
+
+// once per device, with that device current (called from cafe_tables_create)
+static int noalloc_setup(int device) {
+    if (device < 0 || device >= kNoAllocMaxDevices) return 0;      // the entry point then reports "no scratch"
+    if (g_noalloc_ptr[device]) return 0;
+    float *p = nullptr;
+    CAFE_HIP_CHECK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(g_noalloc_scratch)));
+    g_noalloc_ptr[device] = p;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // tables descriptor
 // ------------------------------------------------------------------------------------------------
 extern "C" int cafe_tables_create(cafe_tables_t **out, int num_fields, int dim, int hotn, float *d_w_hot,
@@ -23,6 +43,8 @@ extern "C" int cafe_tables_create(cafe_tables_t **out, int num_fields, int dim, 
     }
     cafe_tables *t = new cafe_tables();
     t->num_fields = num_fields; t->dim = dim; t->hotn = hotn; t->d_w_hot = d_w_hot;
+    CAFE_HIP_CHECK(hipGetDevice(&t->device));
+    if (noalloc_setup(t->device)) { delete t; return 1; }
     std::vector<int64_t> base(num_fields + 1, 0);
     for (int f = 0; f < num_fields; ++f) {
         if (hash_size[f] <= 0) { set_error("cafe_tables_create: hash_size[%d] = %d", f, hash_size[f]); delete t; return 1; }
@@ -301,6 +323,24 @@ static int scores_common(cafe_tables_t *t, const float *d_grad_out, int batch, f
 extern "C" int cafe_scores_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_scores, cafe_stream_t stream) {
     if (t->ws_norm.reserve((size_t)t->num_fields * batch * 4 + 16)) return 1;
     return scores_common(t, d_grad_out, batch, t->ws_norm.as<float>(), d_scores, nullptr, (hipStream_t)stream);
+}
+
+// cafe_scores_dev for callers that cannot allocate (HIP graph capture, tight serving loops): same kernels, the norms
+// go to this GPU's copy of g_noalloc_scratch.  No hipMalloc/hipFree here or below.
+extern "C" int cafe_scores_noalloc_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_scores,
+                                       cafe_stream_t stream) {
+    const long total = (long)t->num_fields * batch;
+    if (batch < 0 || total > kNoAllocMaxLookups) {
+        set_error("cafe_scores_noalloc_dev: %ld lookups exceed the fixed scratch of %d (use cafe_scores_dev)", total,
+                  kNoAllocMaxLookups);
+        return 1;
+    }
+    int dev = -1;
+    CAFE_HIP_CHECK(hipGetDevice(&dev));
+    if (dev != t->device) { set_error("cafe_scores_noalloc_dev: tables belong to device %d, current is %d", t->device, dev); return 1; }
+    float *scratch = dev >= 0 && dev < kNoAllocMaxDevices ? g_noalloc_ptr[dev] : nullptr;
+    if (!scratch) { set_error("cafe_scores_noalloc_dev: no scratch on device %d", dev); return 1; }
+    return scores_common(t, d_grad_out, batch, scratch, d_scores, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int cafe_grad_norm_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_norms, float *d_field_sums,

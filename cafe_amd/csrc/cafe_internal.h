@@ -92,6 +92,7 @@ struct cafe_sketch {
 };
 
 struct cafe_tables {
+    int device = 0;
     int num_fields = 0, dim = 0, hotn = 0;
     float *d_w_hot = nullptr;
     float **d_w_cold = nullptr;      // device array [F] of device pointers

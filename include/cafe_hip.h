@@ -148,6 +148,13 @@ int cafe_forward_ml_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_loc
  * ||g_i|| * batch / sum_j ||g_j|| over field f.  d_grad_out: [num_fields, batch, dim]. */
 int cafe_scores_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_scores, cafe_stream_t stream);
 
+/* No counterpart in the reference.  cafe_scores_dev for callers that cannot allocate -- code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc: same kernels, same results, but the per-lookup norms (the
+ * workspace cafe_scores_dev allocates and grows) live in a fixed 4 MiB device array inside the library, one copy per
+ * GPU.  Allocates nothing; fails with a clear error when num_fields * batch > 1 048 576 lookups.  Every call on a GPU
+ * shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+int cafe_scores_noalloc_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_scores, cafe_stream_t stream);
+
 /* sk_embedding_bag.py:199-208: for every lookup with d_ins != 0 whose id now reads hot,
  * W_hot[slot] = W_cold[f][local_id % hash_size[f]] (pre-update cold row; local id).
  * Arrays are the full [num_fields*batch] ones; only fields [first_field, first_field+n_fields) are visited,
