@@ -48,7 +48,8 @@ struct DevState {
     // scratch written by kernels of the current call
     int32_t maxpart, fallback, rounds;               // maxpart: largest partition of the last parallel insert
     int32_t cadence_miss;    // cumulative: call boundaries at which sketch.cpp:291 would have reset but the host had not
-    int32_t pad[4];
+    int32_t pad[4];          // [0] cumulative: batches given to the in-order kernel, [1] rounds in total, [2] largest round
+                             // count, [3] largest hot-bypass partition of the last parallel insert
     int32_t bad_commit;      // cumulative: staged entries the commit kernel refused (index out of range) -- always 0
     int32_t why[3];          // cumulative, batches given to the in-order kernel (or rejected): [0] a workspace limit,
                              // [1] the rounds that were enqueued did not settle it, [2] the free list changed state
@@ -63,7 +64,10 @@ struct Mirror {
     uint32_t cross;     // threshold crossings (real_n growth) of that call
     uint32_t pops;      // free-list pops of that call
     uint32_t rejected;  // 1: a call issued "to be verified" was not applied (tables and scalars untouched)
-    uint32_t pad[3];
+    uint32_t reason;    // why it was rejected: 1 a workspace limit, 2 rounds did not settle, 3 free list changed state,
+                        // 4 sketch.cpp:291 fires on an inner boundary (the step has to be issued call by call)
+    uint32_t moves;     // moves out of the LRU table in round 1
+    uint32_t got;       // newly hot ids (ins[] != 0)
 };
 
 __host__ __device__ inline int hash_main(uint32_t x, int n1) { return (int)((long long)x * kHashMul % n1); }
@@ -298,6 +302,85 @@ __device__ inline int lru_place(LruR &b, int victim, uint32_t x, float c, float 
     CAFE_SET4(b.c0, b.c1, b.c2, b.c3, victim, 1.0f);          // not c: sketch.cpp:198
     CAFE_SET4(b.d0, b.d1, b.d2, b.d3, victim, dic);
     return got;
+}
+
+// ---- the batch in order, one lane (sketch.cpp:292-294 with insert() :211-231 inlined) -----------------------------
+struct SerialCtx {
+    uint32_t *fifo;
+    uint32_t cap, head, len;
+    int32_t num, real_n, clk;
+    __device__ bool can_pop() const { return len > 0; }
+    __device__ int32_t pop() {
+        uint32_t v = fifo[head];
+        head = head + 1 == cap ? 0 : head + 1;
+        --len;
+        ++num;
+        return (int32_t)v;
+    }
+    __device__ void push(int32_t d) {
+        uint32_t pos = head + len;
+        if (pos >= cap) pos -= cap;
+        fifo[pos] = (uint32_t)d;
+        ++len;
+    }
+    __device__ int32_t tick() { return ++clk; }
+    __device__ void crossed() { ++real_n; }
+};
+
+// score of batch position i: vals[i] (1 when vals == nullptr, batch_insert), scaled by seg / fsum[i / seg] when the
+// caller passes per-field sums (sk_embedding_bag.py:189: gn * N / sum(gn)).  The same expression everywhere a score is
+// formed, so that every kernel sees the same float.
+struct ScoreSrc {
+    const float *vals;
+    const float *fsum;      // per-field sums (global or LDS), or nullptr
+    int seg;
+    __device__ float at(uint32_t i) const {
+        float c = vals ? vals[i] : 1.0f;
+        if (fsum) c = c * (float)seg / fsum[i / (uint32_t)seg];
+        return c;
+    }
+};
+
+__device__ inline int serial_insert_range(MainBucket *mt, LruBucket *lt, int n1, int n2, float thr, uint32_t gflip, SerialCtx &ctx,
+                                          const int32_t *__restrict__ ids, const ScoreSrc &sc, int n, int32_t *__restrict__ ins,
+                                          int seg, double reset_at) {
+    int missed = 0;
+    for (int i = 0; i < n; ++i) {
+        if (seg > 0 && i > 0 && i % seg == 0 && (double)ctx.real_n > reset_at) missed = 1;
+        uint32_t x = (uint32_t)ids[i];
+        float c = sc.at((uint32_t)i);
+        int k = hash_main(x, n1);
+        MainR b;
+        load_main(b, &mt[k]);
+        sync_flip(b, gflip);
+        int r = main_probe(b, x, c, thr, ctx);
+        store_main(&mt[k], b);           // also persists the lazy decay on a miss (sketch.cpp:213)
+        if (r >= 0) { ins[i] = r; continue; }
+        int k2 = hash_lru(x, n2);
+        LruR l;
+        load_lru(l, &lt[k2]);
+        sync_flip(l, gflip);
+        MoveReq mv;
+        int f = lru_find(l, x), got;
+        if (f >= 0) {
+            got = lru_hit(l, f, c, thr, ctx, mv);
+        } else {
+            lru_evict(l, -f - 1, mv);
+        }
+        if (mv.kind) {
+            int km = hash_main(mv.x, n1);
+            MainR m;
+            load_main(m, &mt[km]);
+            sync_flip(m, gflip);
+            int ok = main_move(m, mv.x, mv.cnt, mv.dic, ctx);
+            store_main(&mt[km], m);
+            if (mv.kind == 1 && !ok) got = 0;
+        }
+        if (f < 0) got = lru_place(l, -f - 1, x, c, thr, ctx);
+        store_lru(&lt[k2], l);
+        ins[i] = got;
+    }
+    return missed;
 }
 
 // sketch.cpp:118-128

@@ -17,8 +17,9 @@ using namespace cafe;
 // the symbol, never a device address: host code uses the per-device pointer hipGetSymbolAddress returned.
 // ------------------------------------------------------------------------------------------------
 constexpr int kNoAllocMaxLookups = 1 << 20;
+constexpr int kNoAllocMaxFields = 128;        // x 32 partial sums per field behind the norms
 constexpr int kNoAllocMaxDevices = 64;
-static __device__ __align__(256) float g_noalloc_scratch[kNoAllocMaxLookups];
+static __device__ __align__(256) float g_noalloc_scratch[kNoAllocMaxLookups + kNoAllocMaxFields * 32];
 static float *g_noalloc_ptr[kNoAllocMaxDevices];      // [device] -> address of that device's copy, nullptr = not looked up
 
 // once per device, with that device current (called from cafe_tables_create)
@@ -65,14 +66,14 @@ extern "C" int cafe_tables_create(cafe_tables_t **out, int num_fields, int dim, 
 
 extern "C" int cafe_tables_set_timing(cafe_tables_t *t, int on) {
     if (on && !t->ev_t[0][0])
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 4; ++k)
             for (int j = 0; j < 2; ++j) CAFE_HIP_CHECK(hipEventCreate(&t->ev_t[k][j]));
     t->timing = on ? 1 : 0;
     return 0;
 }
 
 extern "C" int cafe_tables_kernel_ms(cafe_tables_t *t, int which, float *ms) {
-    if (which < 0 || which > 1 || !t->ev_t[which][0]) { set_error("cafe_tables_kernel_ms: timing was not enabled"); return 1; }
+    if (which < 0 || which > 3 || !t->ev_t[which][0]) { set_error("cafe_tables_kernel_ms: timing was not enabled"); return 1; }
     CAFE_HIP_CHECK(hipEventSynchronize(t->ev_t[which][1]));
     CAFE_HIP_CHECK(hipEventElapsedTime(ms, t->ev_t[which][0], t->ev_t[which][1]));
     return 0;
@@ -81,12 +82,12 @@ extern "C" int cafe_tables_kernel_ms(cafe_tables_t *t, int which, float *ms) {
 extern "C" int cafe_tables_destroy(cafe_tables_t *t) {
     if (!t) return 0;
     (void)hipDeviceSynchronize();
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 4; ++k)
         for (int j = 0; j < 2; ++j)
             if (t->ev_t[k][j]) (void)hipEventDestroy(t->ev_t[k][j]);
     if (t->ev_plan) (void)hipEventDestroy(t->ev_plan);
     (void)hipFree(t->d_w_cold); (void)hipFree(t->d_id_offset); (void)hipFree(t->d_hash_size); (void)hipFree(t->d_cold_base);
-    t->ws_norm.release(); t->ws_bwd_a.release(); t->ws_bwd_b.release(); t->ws_bwd_c.release(); t->ws_bwd_d.release();
+    t->ws_norm.release(); t->ws_psum.release(); t->ws_bwd_a.release(); t->ws_bwd_b.release(); t->ws_bwd_c.release(); t->ws_bwd_d.release();
     t->ws_misc.release();
     delete t;
     return 0;
@@ -255,56 +256,92 @@ extern "C" int cafe_forward_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const in
 
 // ------------------------------------------------------------------------------------------------
 // scores: sk_embedding_bag.py:178-189, intended semantics: the L2 norm of each lookup's own
-// output-gradient row, scaled per field so that scores average 1.  Two deterministic passes.
+// output-gradient row, scaled per field so that scores average 1.
+// One pass over the gradient: a workgroup takes a contiguous run of one field's rows, writes their norms and the
+// run's partial sum; a field's sum is the sum of its <= 32 partials in run order, formed where it is needed (the
+// insert's owners, k_scale) -- always the same floats, no second pass over the norms and no extra launch.
 // ------------------------------------------------------------------------------------------------
+constexpr int kMaxNormParts = 32;
+
+static void norm_geometry(int batch, int *nparts, int *rows) {
+    int np = std::min(std::max((batch + 255) / 256, 1), kMaxNormParts);
+    *rows = (batch + np - 1) / np;
+    *nparts = (batch + *rows - 1) / *rows;
+}
+
 template <int LPG>
-__global__ void __launch_bounds__(256) k_grad_norm(const float *__restrict__ g, int total, int dim, float *__restrict__ gn) {
-    const int lig = threadIdx.x % LPG;
-    const int groups = (gridDim.x * blockDim.x) / LPG;
+__global__ void __launch_bounds__(256) k_grad_norm(const float *__restrict__ g, int batch, int rows, int dim,
+                                                   float *__restrict__ gn, float *__restrict__ psum) {
+    constexpr int G = 256 / LPG;                 // row groups of the workgroup
+    __shared__ float gs[G];
+    const int part = blockIdx.x, f = blockIdx.y, nparts = gridDim.x;
+    const int lig = threadIdx.x % LPG, grp = threadIdx.x / LPG;
     const int dim4 = dim >> 2;
-    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) / LPG; i < total; i += groups) {
-        const float4 *r = reinterpret_cast<const float4 *>(g + (size_t)i * dim);
-        float acc = 0.f;
-        for (int c = lig; c < dim4; c += LPG) {
-            float4 v = r[c];
-            acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
+    const int r0 = part * rows, r1 = min(r0 + rows, batch);
+    const size_t fbase = (size_t)f * batch;
+    float run = 0.f;
+    // four rows per step and group: their loads are independent
+    for (int r = r0 + grp; r < r1; r += 4 * G) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * G;
+            if (rr < r1) {
+                const float4 *row = reinterpret_cast<const float4 *>(g + (fbase + rr) * dim);
+                for (int c = lig; c < dim4; c += LPG) {
+                    const float4 v = row[c];
+                    acc[u] += v.x * v.x; acc[u] += v.y * v.y; acc[u] += v.z * v.z; acc[u] += v.w * v.w;
+                }
+            }
         }
 #pragma unroll
-        for (int o = LPG >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, LPG);
-        if (lig == 0) gn[i] = sqrtf(acc);
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int o = LPG >> 1; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, LPG);
+            const int rr = r + u * G;
+            if (rr < r1) {
+                const float nv = sqrtf(acc[u]);
+                if (lig == 0) gn[fbase + rr] = nv;
+                run += nv;
+            }
+        }
     }
-}
-
-// one workgroup per field: fixed-order sum of the field's norms, then s_i = gn_i * batch / sum
-__global__ void __launch_bounds__(1024) k_field_scale(const float *__restrict__ gn, int batch, float *__restrict__ scores,
-                                                      float *__restrict__ sums) {
-    __shared__ float part[1024];
-    const int f = blockIdx.x;
-    const float *src = gn + (size_t)f * batch;
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < batch; i += blockDim.x) acc += src[i];
-    part[threadIdx.x] = acc;
+    if (lig == 0) gs[grp] = run;
     __syncthreads();
-    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
-        __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = 0.f;
+        for (int k = threadIdx.x; k < G; k += 64) v += gs[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (threadIdx.x == 0) psum[(size_t)f * nparts + part] = v;
     }
-    const float sum = part[0];
-    if (sums && threadIdx.x == 0) sums[f] = sum;
-    if (!scores) return;
-    const float nb = (float)batch;
-    float *dst = scores + (size_t)f * batch;
-    for (int i = threadIdx.x; i < batch; i += blockDim.x) dst[i] = src[i] * nb / sum;
 }
 
-static int scores_common(cafe_tables_t *t, const float *d_grad_out, int batch, float *gn, float *d_scores, float *d_sums,
-                         hipStream_t st) {
-    const int total = t->num_fields * batch;
-    if (total <= 0) return 0;
+// s_i = gn_i * batch / sum (the expression of cafe_core.h::ScoreSrc); sums[f] on request
+__global__ void __launch_bounds__(256) k_scale(const float *__restrict__ gn, const float *__restrict__ psum, int nparts,
+                                               int batch, int total, float *__restrict__ scores, float *__restrict__ sums,
+                                               int num_fields) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sums && i < num_fields) {
+        float acc = 0.f;
+        for (int j = 0; j < nparts; ++j) acc += psum[(size_t)i * nparts + j];
+        sums[i] = acc;
+    }
+    if (!scores || i >= total) return;
+    const int f = i / batch;
+    float acc = 0.f;
+    for (int j = 0; j < nparts; ++j) acc += psum[(size_t)f * nparts + j];
+    scores[i] = gn[i] * (float)batch / acc;
+}
+
+// norms and partial sums of one step: gn [F * batch], psum [F * nparts]
+static int norms_common(cafe_tables_t *t, const float *d_grad_out, int batch, float *gn, float *psum, int *nparts_out,
+                        hipStream_t st) {
+    int nparts, rows;
+    norm_geometry(batch, &nparts, &rows);
+    *nparts_out = nparts;
+    if (t->num_fields * batch <= 0) return 0;
     const int lpg = lanes_per_row(t->dim);
-    const long threads = (long)total * lpg;
-    const int blocks = (int)std::min<long>((threads + 255) / 256, 256 * 16);
-#define CAFE_GN(L) hipLaunchKernelGGL(k_grad_norm<L>, dim3(blocks), dim3(256), 0, st, d_grad_out, total, t->dim, gn)
+#define CAFE_GN(L) hipLaunchKernelGGL(k_grad_norm<L>, dim3(nparts, t->num_fields), dim3(256), 0, st, d_grad_out, batch, rows, t->dim, gn, psum)
     switch (lpg) {
         case 1: CAFE_GN(1); break;
         case 2: CAFE_GN(2); break;
@@ -315,24 +352,36 @@ static int scores_common(cafe_tables_t *t, const float *d_grad_out, int batch, f
         default: CAFE_GN(64); break;
     }
 #undef CAFE_GN
-    hipLaunchKernelGGL(k_field_scale, dim3(t->num_fields), dim3(1024), 0, st, gn, batch, d_scores, d_sums);
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int scores_common(cafe_tables_t *t, const float *d_grad_out, int batch, float *gn, float *psum, float *d_scores,
+                         float *d_sums, hipStream_t st) {
+    const int total = t->num_fields * batch;
+    if (total <= 0) return 0;
+    int nparts;
+    if (norms_common(t, d_grad_out, batch, gn, psum, &nparts, st)) return 1;
+    hipLaunchKernelGGL(k_scale, dim3((std::max(total, t->num_fields) + 255) / 256), dim3(256), 0, st, gn, psum, nparts, batch,
+                       total, d_scores, d_sums, t->num_fields);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 extern "C" int cafe_scores_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_scores, cafe_stream_t stream) {
-    if (t->ws_norm.reserve((size_t)t->num_fields * batch * 4 + 16)) return 1;
-    return scores_common(t, d_grad_out, batch, t->ws_norm.as<float>(), d_scores, nullptr, (hipStream_t)stream);
+    if (t->ws_norm.reserve(((size_t)t->num_fields * batch + (size_t)t->num_fields * kMaxNormParts) * 4 + 16)) return 1;
+    float *gn = t->ws_norm.as<float>();
+    return scores_common(t, d_grad_out, batch, gn, gn + (size_t)t->num_fields * batch, d_scores, nullptr, (hipStream_t)stream);
 }
 
 // cafe_scores_dev for callers that cannot allocate (HIP graph capture, tight serving loops): same kernels, the norms
-// go to this GPU's copy of g_noalloc_scratch.  No hipMalloc/hipFree here or below.
+// and partial sums go to this GPU's copy of g_noalloc_scratch.  No hipMalloc/hipFree here or below.
 extern "C" int cafe_scores_noalloc_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_scores,
                                        cafe_stream_t stream) {
     const long total = (long)t->num_fields * batch;
-    if (batch < 0 || total > kNoAllocMaxLookups) {
-        set_error("cafe_scores_noalloc_dev: %ld lookups exceed the fixed scratch of %d (use cafe_scores_dev)", total,
-                  kNoAllocMaxLookups);
+    if (batch < 0 || total > kNoAllocMaxLookups || t->num_fields > kNoAllocMaxFields) {
+        set_error("cafe_scores_noalloc_dev: %ld lookups in %d fields exceed the fixed scratch of %d lookups, %d fields "
+                  "(use cafe_scores_dev)", total, t->num_fields, kNoAllocMaxLookups, kNoAllocMaxFields);
         return 1;
     }
     int dev = -1;
@@ -340,12 +389,13 @@ extern "C" int cafe_scores_noalloc_dev(cafe_tables_t *t, const float *d_grad_out
     if (dev != t->device) { set_error("cafe_scores_noalloc_dev: tables belong to device %d, current is %d", t->device, dev); return 1; }
     float *scratch = dev >= 0 && dev < kNoAllocMaxDevices ? g_noalloc_ptr[dev] : nullptr;
     if (!scratch) { set_error("cafe_scores_noalloc_dev: no scratch on device %d", dev); return 1; }
-    return scores_common(t, d_grad_out, batch, scratch, d_scores, nullptr, (hipStream_t)stream);
+    return scores_common(t, d_grad_out, batch, scratch, scratch + kNoAllocMaxLookups, d_scores, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int cafe_grad_norm_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_norms, float *d_field_sums,
                                   cafe_stream_t stream) {
-    return scores_common(t, d_grad_out, batch, d_norms, nullptr, d_field_sums, (hipStream_t)stream);
+    if (t->ws_psum.reserve((size_t)t->num_fields * kMaxNormParts * 4 + 16)) return 1;
+    return scores_common(t, d_grad_out, batch, d_norms, t->ws_psum.as<float>(), nullptr, d_field_sums, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -393,6 +443,58 @@ extern "C" int cafe_migrate_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const in
     hipLaunchKernelGGL(k_migrate, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_main,
                        make_fastmod(s->n1), t->d_w_hot, t->d_w_cold, t->d_hash_size, t->d_id_offset, nullptr, d_gids,
                        d_fields, d_ins, 1, 0, n, t->dim);
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// The same for the lookups the parallel insert listed as newly hot (cafe_insert_par.hip: got list), LPG lanes per row.
+// A count of 0xffffffff means the batch was walked in order (no list): then ins[] is scanned.
+template <int LPG>
+__global__ void __launch_bounds__(256) k_migrate_list(const MainBucket *__restrict__ mt, FastMod fm1, float *__restrict__ w_hot,
+                                                      float *const *__restrict__ w_cold, const int32_t *__restrict__ hash_size,
+                                                      const int64_t *__restrict__ local_ids, const int32_t *__restrict__ gids,
+                                                      const int32_t *__restrict__ ins, int batch, int total, int dim,
+                                                      const uint32_t *__restrict__ gotcount, const uint32_t *__restrict__ gotlist) {
+    const uint32_t count = *gotcount;
+    const int groups = (gridDim.x * blockDim.x) / LPG, gi = (blockIdx.x * blockDim.x + threadIdx.x) / LPG, lig = threadIdx.x % LPG;
+    const bool scan = count == 0xffffffffu;
+    const int n = scan ? total : (int)min(count, (uint32_t)total);
+    for (int e = gi; e < n; e += groups) {
+        const int i = scan ? e : (int)gotlist[e];
+        if (i >= total || !ins[i]) continue;
+        const uint32_t x = (uint32_t)gids[i];
+        const int4 *p = reinterpret_cast<const int4 *>(&mt[fast_hash(x, fm1)]);
+        const int4 v = p[0], d = p[1];
+        const int32_t val[4] = {v.x, v.y, v.z, v.w}, dic[4] = {d.x, d.y, d.z, d.w};
+        const int32_t q = query_bucket(val, dic, x);            // the re-query of sk_embedding_bag.py:201-204
+        if (q >= 0) continue;
+        const int f = i / batch;
+        const int64_t src_row = local_ids[i] % (int64_t)hash_size[f];     // LOCAL id: sk_embedding_bag.py:207
+        const float4 *src = reinterpret_cast<const float4 *>(w_cold[f] + (size_t)src_row * dim);
+        float4 *dst = reinterpret_cast<float4 *>(w_hot + (size_t)(-q) * dim);
+        for (int c = lig; c < (dim >> 2); c += LPG) dst[c] = src[c];
+    }
+}
+
+static int migrate_list(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids, const int32_t *d_ins,
+                        int batch, hipStream_t st) {
+    const int total = t->num_fields * batch;
+    const uint32_t *cnt = cafe::par_gotcount(s), *lst = cafe::par_gotlist(s);
+    if (!cnt || total <= 0) return 0;
+    FastMod fm1 = make_fastmod(s->n1);
+#define CAFE_MIG(L)                                                                                                        \
+    hipLaunchKernelGGL(k_migrate_list<L>, dim3(64), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold, t->d_hash_size, \
+                       d_local_ids, d_gids, d_ins, batch, total, t->dim, cnt, lst)
+    switch (lanes_per_row(t->dim)) {
+        case 1: CAFE_MIG(1); break;
+        case 2: CAFE_MIG(2); break;
+        case 4: CAFE_MIG(4); break;
+        case 8: CAFE_MIG(8); break;
+        case 16: CAFE_MIG(16); break;
+        case 32: CAFE_MIG(32); break;
+        default: CAFE_MIG(64); break;
+    }
+#undef CAFE_MIG
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -526,12 +628,16 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                                                       const unsigned long long *__restrict__ items,
                                                       const int32_t *__restrict__ fields, const float *__restrict__ grad,
                                                       float *__restrict__ w_hot, float *const *__restrict__ w_cold,
-                                                      const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr) {
+                                                      const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr,
+                                                      const int32_t *__restrict__ skip_if_2) {
     __shared__ __attribute__((aligned(16))) unsigned long long key[kBwdCap];
     __shared__ float4 bpart[2][VPL][256];      // border partial sums: [0] head of a group's range, [1] tail
     __shared__ int bflag[256];
     const int tid = threadIdx.x;
     if (blockIdx.x >= tiles[0]) return;
+    // queued behind an insert whose verdict the host has not seen yet: if the device rejected it (DevState::fallback
+    // == 2) the host issues the step again, and this update with it
+    if (skip_if_2 && *skip_if_2 == 2) return;
     // the tile index is kept in 8 bits; a partition with more tiles lets its last workgroup walk the rest
     const uint32_t tl = tiles[1 + blockIdx.x];
     const int p = (int)(tl >> 8), tile = (int)(tl & 255u);
@@ -690,7 +796,8 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
 // The backward in two parts: the partition passes (they read the routing only) on `pst`, the segment kernel (gradient
 // rows in, table rows updated) on `st`.  With pst != st the caller orders st behind t->ev_plan, recorded here on pst.
 static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,
-                           int batch, int total, float lr, hipStream_t st, hipStream_t pst, int part = 3) {
+                           int batch, int total, float lr, hipStream_t st, hipStream_t pst, int part = 3,
+                           const int32_t *skip_if_2 = nullptr) {
     if (total <= 0) return 0;
     const int64_t rows = (int64_t)t->hotn + t->total_cold_rows;
     if (rows >= (int64_t)0xFFFFFFFFLL) { set_error("cafe_backward_sgd_dev: more than 2^32 table rows"); return 1; }
@@ -724,7 +831,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     if (pst != st) CAFE_HIP_CHECK(hipStreamWaitEvent(st, t->ev_plan, 0));
 #define CAFE_SEG(L, V)                                                                                                   \
     hipLaunchKernelGGL((k_bwd_segments<L, V>), dim3(max_tiles), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
-                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr)
+                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_if_2)
     if (t->timing) (void)hipEventRecord(t->ev_t[1][0], st);
     if (vpl == 1) {
         switch (lpg) {
@@ -764,98 +871,104 @@ extern "C" int cafe_backward_sgd_gid_dev(cafe_tables_t *t, const int32_t *d_fiel
 // per_field != 0: the sketch is fed as the reference feeds it, one batch_insert_val per field (dlrm_s_pytorch.py:
 // 734-738): decay and batch counter advance once per field and sketch.cpp:291 is evaluated at every field boundary.
 // Without a flip or a reset on an inner boundary, F calls over consecutive parts of the id stream equal ONE in-order
-// pass over the whole stream, so the step still runs as one parallel insert; the host proves "no inner flip" from
-// its own counters and "no inner reset" from its bound on real_n (cafe_sketch.hip), the closing kernel re-checks
-// the boundaries against the real value (counter [6]).  A step that may hold an inner flip or reset, or that runs
-// while Threshold <= 1 (migration then depends on the state after each field), is issued field by field.  per_field == 0: one batch_insert_val for the whole step (decay and reset once per step).
+// pass over the whole stream, so the step runs as one parallel insert: the host proves "no flip in these F calls" from
+// its own counters; the reset test at the first boundary is made on the exact real_n (the host waits for every step's
+// verdict, so its snapshot is current); the inner boundaries are checked by the commit kernel from per-field crossing
+// counts BEFORE anything is applied, and a step in which one fires is rejected and issued again field by field.  A
+// step that runs while Threshold <= 1 (migration then depends on the state after each field) is issued field
+// by field from the start.  per_field == 0: one batch_insert_val for the whole step (decay and reset once per step).
+//
+// The migration and the SGD update are queued behind the insert before the host waits for the verdict, so the device
+// does not idle; both do nothing if the device rejected the insert (the host then repeats them behind the repair).
 extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
                                         const int32_t *d_que, const float *d_grad_out, int batch, float lr, float *d_scores,
                                         int32_t *d_ins, int per_field, cafe_stream_t stream) {
     const int F = t->num_fields;
     const int total = F * batch;
     hipStream_t st = (hipStream_t)stream;
-    // fuse: the step is proven free of inner flips and resets and runs as one insert.  verify: it may hold a reset
-    // boundary (or a free list about to run dry); it still runs as one insert, but the device checks the boundaries
-    // BEFORE anything is committed and rejects the batch if one fires or if the batch cannot be settled in parallel;
-    // the host waits for the verdict and issues a rejected step again field by field.  Neither: field by field.
-    bool fuse = true, verify = false;
-    if (per_field && F > 1 && batch > 0) {
-        fuse = F <= kMaxSeg && s->opt_fuse_fields && !s->opt_serial && total <= (1 << 21) && cafe::threshold_known_above_one(s);
-        bool flip_inside = false, flip_first = false;
+    if (total <= 0) return 0;
+    const bool cadence = per_field && F > 1;
+    bool fuse = F <= kMaxSeg && s->opt_fuse_fields && !s->opt_serial && total <= cafe::kParMaxIds;
+    if (fuse) {
         double d = s->decay;
-        for (int f = 0; f < F; ++f) {                    // sketch.cpp:284-289 for the F calls ahead
+        for (int f = 0; f < (cadence ? F : 1); ++f) {                    // sketch.cpp:284-289 for the calls ahead
             d *= s->alpha;
-            if (d > kDecayV) { d /= kDecayV; (f > 0 ? flip_inside : flip_first) = true; }
+            if (d > kDecayV) { d /= kDecayV; fuse = false; }             // a flip: call by call
         }
-        // a flip at the first field is this call's own; the step then runs under Threshold / V
-        if (flip_inside || (flip_first && !((float)((double)s->host_thr / kDecayV) > 1.0f))) fuse = false;
-        if (fuse) {
-            bool sure = true;
-            // A free list that may run dry inside the batch would send the whole batch to the in-order kernel
-            // (cafe_insert_par.hip); typical right after a reset, until the few slots it freed are handed out.
-            (void)cafe::real_n_bound(s);                 // consumes the newest snapshot
-            if (s->fifo_hint < 0 || (s->fifo_hint > 0 && s->fifo_hint < cafe::growth_estimate(s, total))) sure = false;
-            if (sure && s->adjust) {
-                const double at = s->lim * 1.2;
-                long long start = cafe::real_n_bound(s);
-                if ((double)(start + cafe::growth_estimate(s, total)) > at) {
-                    if (cafe::real_n_exact(s, &start)) return 1;
-                    if ((double)start > at) start = s->lim;              // the first field's call begins with a reset
-                    sure = !((double)(start + cafe::growth_estimate(s, total)) > at);
-                }
-            }
-            if (!sure) { fuse = false; verify = !flip_first && s->opt_verify; }
-        }
-    }
-    bool scores_done = false, plan_done = false;
-    hipStream_t side = st;
-    if (fuse || verify) {
-        // What does not depend on this step's gradients runs on the sketch's second stream, beside the score kernels
-        // and the owner rounds: the head of the insert (per-call scalars, partition counts: ids and pre-batch tables
-        // only) and the partition passes of the backward (routing of the forward only).  Everything that was queued on
-        // `stream` before this call (the previous step's commit and SGD, this step's forward) is ordered before them.
-        // (small steps are launch-bound: the cross-stream dependencies cost more than the overlap returns)
-        if (s->opt_overlap && s->side_stream && s->side_stream != st && total >= 32768) side = s->side_stream;
-        if (side != st) {
-            CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, st));
-            CAFE_HIP_CHECK(hipStreamWaitEvent(side, s->ev_head_fork, 0));
-        }
-        if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
-        scores_done = true;
-        const double decay0 = s->decay;
-        const int batch_num0 = s->batch_num;
-        s->seg_len = per_field && F > 1 ? batch : 0;
-        s->verify_mode = verify ? 1 : 0;
-        const int rc = cafe::insert_dev_on(s, d_gids, d_scores, total, d_ins, st, (s->opt_overlap & 1) ? side : st);
-        s->seg_len = 0;
-        s->verify_mode = 0;
-        if (rc) return 1;
-        if (side != st) {
-            if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 1)) return 1;
-            plan_done = true;
-        }
-        if (verify) {
-            bool rejected = false;
-            if (cafe::last_insert_rejected(s, &rejected)) return 1;
-            if (rejected) {             // nothing was applied on the device: take the call counters back as well
-                s->decay = decay0;
-                s->batch_num = batch_num0;
-                s->counters[0]--;
-                fuse = false;
-            } else {
-                fuse = true;
-            }
-        }
+        if (cadence && !cafe::threshold_known_above_one(s)) fuse = false;
     }
     if (fuse) {
-        if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, 0, t->num_fields, stream)) return 1;
-    } else {
-        if (!scores_done && cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
-        for (int f = 0; f < F; ++f) {
-            const size_t o = (size_t)f * batch;
-            if (cafe_insert_dev(s, d_gids + o, d_scores + o, batch, d_ins + o, stream)) return 1;
-            if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, f, 1, stream)) return 1;
+        // What does not depend on this step's gradients runs on the sketch's second stream, beside the norm kernel: the
+        // plan of the insert (ids and pre-batch tables only) and the partition passes of the backward (routing of the
+        // forward only).  Everything that was queued on `stream` before this call (the previous step's commit and SGD,
+        // this step's forward) is ordered before them.  (Small steps are launch-bound: the cross-stream dependencies
+        // cost more than the overlap returns.)
+        hipStream_t side = st;
+        if (s->opt_overlap && s->side_stream && s->side_stream != st && total >= 32768) side = s->side_stream;
+        const size_t norm_floats = (size_t)total + (size_t)F * kMaxNormParts;
+        if (t->ws_norm.reserve(norm_floats * 4 + 16) || cafe::par_prepare(s, total)) return 1;
+        float *gn = t->ws_norm.as<float>(), *psum = gn + total;
+        const double decay0 = s->decay;
+        const int batch_num0 = s->batch_num;
+        bool plan_done = false;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (side != st) {
+                CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, st));
+                CAFE_HIP_CHECK(hipStreamWaitEvent(side, s->ev_head_fork, 0));
+            }
+            int nparts = 0;
+            if (attempt == 0) {
+                if (t->timing) (void)hipEventRecord(t->ev_t[3][0], st);
+                if (norms_common(t, d_grad_out, batch, gn, psum, &nparts, st)) return 1;
+                if (t->timing) (void)hipEventRecord(t->ev_t[3][1], st);
+            } else {
+                int rows;
+                norm_geometry(batch, &nparts, &rows);
+            }
+            s->seg_len = cadence ? batch : 0;
+            s->score_seg = batch;
+            s->verify_mode = 1;
+            if (t->timing) s->ev_chain[0] = t->ev_t[2][0], s->ev_chain[1] = t->ev_t[2][1];
+            const int rc = cafe::insert_dev_on(s, d_gids, gn, psum, nparts, total, d_ins, d_scores, st, (s->opt_overlap & 1) ? side : st);
+            s->seg_len = 0; s->score_seg = 0; s->verify_mode = 0;
+            s->ev_chain[0] = s->ev_chain[1] = nullptr;
+            if (rc) return 1;
+            if (side != st && !plan_done) {
+                if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 1)) return 1;
+                plan_done = true;
+            }
+            if (migrate_list(s, t, d_local_ids, d_gids, d_ins, batch, st)) return 1;
+            if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, plan_done ? side : st, plan_done ? 2 : 3,
+                                &s->d_state->fallback)) return 1;
+            bool rejected = false;
+            int reason = 0;
+            if (cafe::last_insert_verdict(s, &rejected, &reason)) return 1;
+            if (!rejected) { s->force_cap_once = 0; return 0; }
+            // nothing was applied on the device: take the call counters back as well
+            s->decay = decay0;
+            s->batch_num = batch_num0;
+            s->counters[0]--;
+            plan_done = true;                     // the partition passes of the backward stand (they read the routing only)
+            // a workspace limit or too few rounds: once more with the largest owners; anything else: call by call
+            if (attempt == 0 && (reason == 1 || reason == 2) && !s->force_cap) { s->force_cap_once = 8192; continue; }
+            break;
         }
+        s->force_cap_once = 0;
+        // call by call; the scores are in d_scores (the finish kernel writes them whatever the verdict)
+        for (int f = 0; f < (cadence ? F : 1); ++f) {
+            const size_t o = cadence ? (size_t)f * batch : 0;
+            const int nn = cadence ? batch : total;
+            if (cafe_insert_dev(s, d_gids + o, d_scores + o, nn, d_ins + o, stream)) return 1;
+            if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, cadence ? f : 0, cadence ? 1 : F, stream)) return 1;
+        }
+        return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 2);
     }
-    return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, plan_done ? side : st, plan_done ? 2 : 3);
+    if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
+    for (int f = 0; f < (cadence ? F : 1); ++f) {
+        const size_t o = cadence ? (size_t)f * batch : 0;
+        const int nn = cadence ? batch : total;
+        if (cafe_insert_dev(s, d_gids + o, d_scores + o, nn, d_ins + o, stream)) return 1;
+        if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, cadence ? f : 0, cadence ? 1 : F, stream)) return 1;
+    }
+    return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, st);
 }

@@ -47,9 +47,12 @@ struct cafe_sketch {
     uint32_t *d_fifo = nullptr;
     uint32_t fifo_cap = 1;
     cafe::DevState *d_state = nullptr;
-    // upper bound of real_n known to the host without a sync (each inserted id raises real_n by at most 1)
     // options / counters
     int opt_serial = 0, opt_max_rounds = 6, opt_target_items = 320, opt_hot_bypass = 1;
+    int force_cap = 0;                  // option "owner_cap": items an owner workgroup can hold (0 = chosen per call)
+    int force_cap_once = 0;             // ... for the call being issued (a step issued again after a workspace limit)
+    int score_seg = 0;                  // > 0: vals are norms, scaled per segment of score_seg ids (ScoreSrc)
+    hipEvent_t ev_chain[2] = {nullptr, nullptr};    // timing aid: recorded around round 1 .. commit of the next insert
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // workspaces
     cafe::DevBuf ws_reset_keys, ws_reset_keys2, ws_reset_tmp, ws_reset_flags, ws_misc;
@@ -57,29 +60,21 @@ struct cafe_sketch {
     int32_t *h_pinned = nullptr;    // pinned host mirror of DevState, written by the kernel that closes every insert
     int32_t *d_pinned = nullptr;    // the same memory as the device sees it
     hipStream_t last_stream = nullptr;
-    // Second stream of the handle.  The part of an insert that does not need the scores (per-call scalars, reset,
-    // partition counts and offsets) and the partition passes of the backward run there, beside the score kernels and
-    // the owner rounds on the caller's stream (cafe_backward_update_dev).  With CAFE_SIDE_STREAM set the hot bypass
-    // runs there too, beside round 1 of the owners.
+    // Second stream of the handle.  The part of an insert that does not need the scores (the plan: classification,
+    // partition offsets, item records) and the partition passes of the backward run there, beside the score kernel on
+    // the caller's stream (cafe_backward_update_dev).
     hipStream_t side_stream = nullptr;
-    int hot_on_side = 1, opt_overlap = 3;     // measured: 0.318 ms per cfg3 step against 0.330 with one stream
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_head_fork = nullptr, ev_head_join = nullptr;
-    int hint_rounds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // final round counts of recent calls (0 = unknown)
-    int hint_part[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hint_hot[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // largest partitions of recent calls
-    int hint_pos = 0;
-    long round_hist[18] = {0};          // final round of the calls seen through the snapshots (diagnostics)
-    int seen_inorder = 0, generous_calls = 0;   // launch_plan: full rounds and big-partition owners after a fallback
+    int opt_overlap = 3;
+    hipEvent_t ev_head_fork = nullptr, ev_head_join = nullptr;
+    hipEvent_t ev_done = nullptr;       // recorded behind the closing kernel of every insert
+    int ev_done_valid = 0;
     long long last_seen_batch = -1;
-    // real_n as the host knows it without a sync: the last snapshot of the pinned mirror plus a growth estimate for the
-    // calls issued since (see real_n_bound in cafe_sketch.hip)
+    // real_n as the host knows it without a sync: the last snapshot of the pinned mirror plus the ids of the calls
+    // issued since (see real_n_bound in cafe_sketch.hip)
     uint32_t call_seq = 0;              // sequence number of the insert being issued (0 = none yet)
     uint32_t base_seq = 0;              // snapshots older than this are stale (a reset or a state import came later)
     long long base_real_n = 0;          // real_n after call base_seq
-    double rates[32] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-    int rate_pos = 0;                   // crossings per inserted id of the last 32 snapshots seen (1 = not seen yet)
-    uint32_t rate_seen_seq = 0;
     int opt_fuse_fields = 1, opt_verify = 1;
-    int opt_exact_reset = 0;            // 1: count every issued id as a possible crossing (waits more often, never guesses)
     struct Issued { uint32_t seq; int n; };
     Issued issued[64];                  // ring of the most recent calls
     int verify_mode = 0;                // with seg_len: see Geo::verify
@@ -100,32 +95,36 @@ struct cafe_tables {
     int32_t *d_hash_size = nullptr;  // device array [F]
     int64_t *d_cold_base = nullptr;  // device array [F+1]: first row of field f in the unified cold row space
     int64_t total_cold_rows = 0;
-    cafe::DevBuf ws_norm, ws_bwd_a, ws_bwd_b, ws_bwd_c, ws_bwd_d, ws_misc;
-    // optional HIP-event timing of the two bandwidth kernels (bench.py's roofline figures): [0] k_forward, [1] k_bwd_segments
+    cafe::DevBuf ws_norm, ws_psum, ws_bwd_a, ws_bwd_b, ws_bwd_c, ws_bwd_d, ws_misc;
+    // optional HIP-event timing (bench.py's roofline figures): [0] k_forward, [1] k_bwd_segments, [2] the sketch insert
+    // (round 1 .. commit), [3] k_grad_norm
     int timing = 0;
-    hipEvent_t ev_t[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipEvent_t ev_t[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     hipEvent_t ev_plan = nullptr;    // partition passes of the backward done (recorded on the sketch's side stream)
 };
 
 namespace cafe {
+constexpr int kParMaxIds = 1 << 21;     // largest batch of the parallel insert (22-bit time field of its items)
 // cafe_insert_par.hip
-// `pre`: stream for the kernels that do not read the scores (== st: everything in order on st)
-int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st,
-               hipStream_t pre);
-// region the per-call prologue kernel has to zero for a parallel insert of n ids (nullptr: none)
-int par_prepare(cafe_sketch *s, int n, uint32_t **zero, int *zero_words);
+// vals: scores -- or, with psum ([fields][nparts] partial sums per field, seg_len set), per-lookup norms that are scaled
+// where they are consumed (d_scores_out then receives the scores).  `pre`: stream for the kernels that do not read
+// vals (== st: everything in order on st).
+int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const float *d_psum, int nparts, int n,
+               int32_t *d_ins, float *d_scores_out, int flip_now, hipStream_t st, hipStream_t pre);
+int par_prepare(cafe_sketch *s, int n);          // sizes the workspaces (may allocate: before any kernel of the call)
 void par_free(cafe_sketch *s);
+// what the last parallel insert leaves for the migration: number of newly hot lookups (0xffffffff: scan ins[]) and
+// their batch positions
+const uint32_t *par_gotcount(cafe_sketch *s);
+const uint32_t *par_gotlist(cafe_sketch *s);
 // cafe_sketch.hip
-int launch_serial_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
-                         int only_if_fallback, hipStream_t st, const uint32_t *par_totals = nullptr,
-                         const uint32_t *segcross = nullptr);
-// cafe_insert_dev with the score-independent head on `pre`; the caller has made `pre` wait for whatever of `st` the head
-// depends on (the previous insert, the ids) and may have queued the score kernels on `st` behind that point
-long long growth_estimate(const cafe_sketch *s, long long n);
+int launch_serial_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st);
 long long real_n_bound(cafe_sketch *s);
 bool threshold_known_above_one(cafe_sketch *s);
 int real_n_exact(cafe_sketch *s, long long *out);
-int last_insert_rejected(cafe_sketch *s, bool *rejected);
-int insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st,
-                  hipStream_t pre);
+int last_insert_verdict(cafe_sketch *s, bool *rejected, int *reason);
+// cafe_insert_dev with the score-independent head on `pre`; the caller has made `pre` wait for whatever of `st` the head
+// depends on (the previous insert, the ids) and may have queued the score kernel on `st` behind that point
+int insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const float *d_psum, int nparts, int n,
+                  int32_t *d_ins, float *d_scores_out, hipStream_t st, hipStream_t pre);
 }  // namespace cafe

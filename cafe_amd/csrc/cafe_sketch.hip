@@ -114,12 +114,12 @@ __global__ void k_count(const MainBucket *__restrict__ mt, int n1, const int32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-call prologue (sketch.cpp:282-289): the flip decision is made on the host (it depends on the
-// call count only); the threshold lives on the device because reset() rewrites it there.
+// per-call prologue (sketch.cpp:282-289) for the calls that do not go through the parallel insert (which
+// applies it in its own k_offsets): the flip decision is made on the host (it depends on the call count
+// only); the threshold lives on the device because reset() rewrites it there.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_prologue(DevState *st, int flip_now, int gflip, uint32_t *zero, int zero_words) {
-    for (int i = threadIdx.x; i < zero_words; i += blockDim.x) zero[i] = 0;      // control words of the parallel insert
-    if (threadIdx.x == 0) {
+__global__ void k_prologue(DevState *st, int flip_now, int gflip) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (flip_now) st->thr = (float)((double)st->thr / kDecayV);
         st->flip = gflip;
         st->fallback = 0;
@@ -128,143 +128,46 @@ __global__ void __launch_bounds__(1024) k_prologue(DevState *st, int flip_now, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// in-order insert: one lane walks the batch exactly like the reference's loop (sketch.cpp:292-294).
-// It is the definition of correctness on the device, the path for batches the parallel kernels hand
-// back (free list about to run dry, fix-point not reached, workspace overflow) and a test aid.
+// in-order insert: one lane walks the batch exactly like the reference's loop (sketch.cpp:292-294;
+// cafe_core.h::serial_insert_range).  It is the definition of correctness on the device, the path for
+// option "serial_insert" and for batches beyond the parallel insert's size limit, and a test aid.  (The
+// parallel insert runs the same loop inside its closing kernel for a batch it could not settle.)
 // ------------------------------------------------------------------------------------------------
-struct SerialCtx {
-    uint32_t *fifo;
-    uint32_t cap, head, len;
-    int32_t num, real_n, clk;
-    __device__ bool can_pop() const { return len > 0; }
-    __device__ int32_t pop() {
-        uint32_t v = fifo[head];
-        head = head + 1 == cap ? 0 : head + 1;
-        --len;
-        ++num;
-        return (int32_t)v;
-    }
-    __device__ void push(int32_t d) {
-        uint32_t pos = head + len;
-        if (pos >= cap) pos -= cap;
-        fifo[pos] = (uint32_t)d;
-        ++len;
-    }
-    __device__ int32_t tick() { return ++clk; }
-    __device__ void crossed() { ++real_n; }
-};
-
 __global__ void __launch_bounds__(64) k_insert_serial(MainBucket *mt, LruBucket *lt, uint32_t *fifo, uint32_t cap,
                                                       DevState *st, int n1, int n2, const int32_t *__restrict__ ids,
                                                       const float *__restrict__ scores, int n, int32_t *__restrict__ ins,
-                                                      int only_if_fallback, const uint32_t *par_totals, Mirror *host_mirror,
-                                                      uint32_t seq, double reset_at, int seg, const uint32_t *segcross) {
-    if (blockIdx.x != 0) return;
-    const int lane = threadIdx.x;
-    const bool settled = only_if_fallback && !st->fallback;       // uniform
-    if (settled && lane != 0) return;
-    // sketch.cpp:291 is evaluated by the host from a bound on real_n (cafe_insert_dev).  Checked here against the real
-    // value: a call that should have begun with a reset, or -- for a call that stands for one call per `seg` ids --
-    // an inner boundary at which the per-field call would have, is counted, never silently accepted.
+                                                      Mirror *host_mirror, uint32_t seq, double reset_at) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    // sketch.cpp:291 is evaluated by the host from an upper bound of real_n (insert_dev_on).  Checked here against the
+    // real value: a call that should have begun with a reset is counted, never silently accepted.
     const int32_t real_n0 = st->real_n, num0 = st->num;
-    if (only_if_fallback && st->fallback == 2) {          // rejected by k_finish_ranks: nothing was applied
-        if (lane == 0) {
-            host_mirror->st = *st;
-            host_mirror->n = (uint32_t)n; host_mirror->cross = 0; host_mirror->pops = 0; host_mirror->rejected = 1;
-            __threadfence_system();
-            host_mirror->seq = seq;
-        }
-        return;
-    }
-    if (lane == 0 && (double)real_n0 > reset_at) st->cadence_miss += 1;
-    if (settled) {
-        if (seg > 0) {
-            long run = real_n0;
-            const int nseg = (n + seg - 1) / seg;
-            for (int f = 0; f + 1 < nseg && f < kMaxSeg; ++f) {
-                run += segcross[f];
-                if ((double)run > reset_at) { st->cadence_miss += 1; break; }
-            }
-        }
-        // the parallel insert settled: apply its batch totals (pops, pushes, clock ticks, crossings, rounds)
-        st->fifo_head = (uint32_t)(((unsigned long long)st->fifo_head + par_totals[0]) % cap);
-        st->fifo_len = st->fifo_len + par_totals[1] - par_totals[0];
-        st->num += (int32_t)par_totals[0];
-        st->clk += (int32_t)par_totals[2];
-        st->real_n += (int32_t)par_totals[3];
-        st->pad[1] += (int32_t)par_totals[4];
-        if ((int32_t)par_totals[4] > st->pad[2]) st->pad[2] = (int32_t)par_totals[4];
-        host_mirror->st = *st;          // pinned host memory: the host reads it lagging, without a copy or a sync
-        host_mirror->n = (uint32_t)n; host_mirror->cross = par_totals[3]; host_mirror->pops = par_totals[0];
-        host_mirror->rejected = 0;
-        __threadfence_system();
-        host_mirror->seq = seq;
-        return;
-    }
-    if (only_if_fallback && lane == 0) st->pad[0] += 1;          // cumulative: batches handed to the in-order kernel
-    // One lane walks the batch.  (Measured: letting the other lanes pull the buckets of the next 64 ids into the cache
-    // does not shorten the walk -- 1.4 us per id either way: the two dependent loads per id cost an L2 round trip each.)
+    if ((double)real_n0 > reset_at) st->cadence_miss += 1;
+    st->pad[0] += 1;          // cumulative: batches walked in order
+    // (Measured: letting other lanes pull the buckets of the next 64 ids into the cache does not shorten the walk --
+    // 1.4 us per id either way: the two dependent loads per id cost an L2 round trip each.)
     SerialCtx ctx;
     ctx.fifo = fifo; ctx.cap = cap; ctx.head = st->fifo_head; ctx.len = st->fifo_len;
     ctx.num = st->num; ctx.real_n = st->real_n; ctx.clk = st->clk;
-    const float thr = st->thr;
-    const uint32_t gflip = (uint32_t)st->flip;
-    int missed = 0;
-    if (lane != 0) return;
-    {
-      for (int i = 0; i < n; ++i) {
-        if (seg > 0 && i > 0 && i % seg == 0 && (double)ctx.real_n > reset_at) missed = 1;
-        uint32_t x = (uint32_t)ids[i];
-        float c = scores ? scores[i] : 1.0f;
-        int k = hash_main(x, n1);
-        MainR b;
-        load_main(b, &mt[k]);
-        sync_flip(b, gflip);
-        int r = main_probe(b, x, c, thr, ctx);
-        store_main(&mt[k], b);           // also persists the lazy decay on a miss (sketch.cpp:213)
-        if (r >= 0) { ins[i] = r; continue; }
-        int k2 = hash_lru(x, n2);
-        LruR l;
-        load_lru(l, &lt[k2]);
-        sync_flip(l, gflip);
-        MoveReq mv;
-        int f = lru_find(l, x), got;
-        if (f >= 0) {
-            got = lru_hit(l, f, c, thr, ctx, mv);
-        } else {
-            lru_evict(l, -f - 1, mv);
-        }
-        if (mv.kind) {
-            int km = hash_main(mv.x, n1);
-            MainR m;
-            load_main(m, &mt[km]);
-            sync_flip(m, gflip);
-            int ok = main_move(m, mv.x, mv.cnt, mv.dic, ctx);
-            store_main(&mt[km], m);
-            if (mv.kind == 1 && !ok) got = 0;
-        }
-        if (f < 0) got = lru_place(l, -f - 1, x, c, thr, ctx);
-        store_lru(&lt[k2], l);
-        ins[i] = got;
-      }
-    }
+    ScoreSrc sc;
+    sc.vals = scores; sc.fsum = nullptr; sc.seg = 0;
+    serial_insert_range(mt, lt, n1, n2, st->thr, (uint32_t)st->flip, ctx, ids, sc, n, ins, 0, reset_at);
     st->fifo_head = ctx.head; st->fifo_len = ctx.len;
     st->num = ctx.num; st->real_n = ctx.real_n; st->clk = ctx.clk;
-    st->cadence_miss += missed;
+    st->fallback = 1;
     host_mirror->st = *st;
     host_mirror->n = (uint32_t)n; host_mirror->cross = (uint32_t)(ctx.real_n - real_n0);
     host_mirror->pops = (uint32_t)(ctx.num - num0);
-    host_mirror->rejected = 0;
+    host_mirror->rejected = 0; host_mirror->reason = 0; host_mirror->moves = 0; host_mirror->got = 0;
     __threadfence_system();
     host_mirror->seq = seq;
 }
 
 int cafe::launch_serial_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
-                               int only_if_fallback, hipStream_t st, const uint32_t *par_totals, const uint32_t *segcross) {
+                               hipStream_t st) {
     const double reset_at = s->adjust ? s->lim * 1.2 : 1e300;
     hipLaunchKernelGGL(k_insert_serial, dim3(1), dim3(64), 0, st, s->d_main, s->d_lru, s->d_fifo, s->fifo_cap,
-                       s->d_state, s->n1, s->n2, d_ids, d_scores, n, d_ins, only_if_fallback, par_totals,
-                       reinterpret_cast<Mirror *>(s->d_pinned), s->call_seq, reset_at, s->seg_len, segcross);
+                       s->d_state, s->n1, s->n2, d_ids, d_scores, n, d_ins, reinterpret_cast<Mirror *>(s->d_pinned),
+                       s->call_seq, reset_at);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -443,15 +346,11 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     CAFE_HIP_CHECK(hipHostMalloc((void **)&s->h_pinned, 256, hipHostMallocMapped));
     memset(s->h_pinned, 0, 256);
     CAFE_HIP_CHECK(hipHostGetDevicePointer((void **)&s->d_pinned, s->h_pinned, 0));
-    // measured on cfg3: the bypass kernel and round 1 are both limited by LDS residency, so running them side by side
-    // gains nothing; the side stream stays an opt-in
     CAFE_HIP_CHECK(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
-    if (const char *e = getenv("CAFE_SIDE_STREAM")) s->hot_on_side = atoi(e);
     if (const char *e = getenv("CAFE_OVERLAP")) s->opt_overlap = atoi(e);
-    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_fork, hipEventDisableTiming));
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_join, hipEventDisableTiming));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
     if (s->ws_misc.reserve(4096)) return 1;
     CAFE_HIP_CHECK(hipMemset(s->d_main, 0, sizeof(MainBucket) * (size_t)s->n1));
     CAFE_HIP_CHECK(hipMemset(s->d_lru, 0, sizeof(LruBucket) * (size_t)s->n2));
@@ -465,20 +364,14 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
 
 extern "C" int cafe_sketch_destroy(cafe_sketch_t *s) {
     if (!s) return 0;
-    if (getenv("CAFE_DEBUG_ROUNDS")) {
-        fprintf(stderr, "cafe: final rounds seen:");
-        for (int i = 0; i < 18; ++i) if (s->round_hist[i]) fprintf(stderr, " %d:%ld", i, s->round_hist[i]);
-        fprintf(stderr, "\n");
-    }
     (void)hipDeviceSynchronize();
     par_free(s);
     (void)hipFree(s->d_main); (void)hipFree(s->d_lru); (void)hipFree(s->d_fifo); (void)hipFree(s->d_state);
     if (s->h_pinned) (void)hipHostFree(s->h_pinned);
     if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
-    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->ev_head_fork) (void)hipEventDestroy(s->ev_head_fork);
     if (s->ev_head_join) (void)hipEventDestroy(s->ev_head_join);
+    if (s->ev_done) (void)hipEventDestroy(s->ev_done);
     s->ws_reset_keys.release(); s->ws_reset_keys2.release(); s->ws_reset_tmp.release();
     s->ws_reset_flags.release(); s->ws_misc.release();
     delete s;
@@ -490,7 +383,8 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
     else if (!strcmp(name, "max_rounds")) s->opt_max_rounds = value < 1 ? 1 : value;
     else if (!strcmp(name, "target_items")) s->opt_target_items = value < 16 ? 16 : value;
     else if (!strcmp(name, "hot_bypass")) s->opt_hot_bypass = value ? 1 : 0;
-    else if (!strcmp(name, "exact_reset")) s->opt_exact_reset = value ? 1 : 0;
+    else if (!strcmp(name, "exact_reset")) (void)value;          // kept for callers of older builds: the decision is always exact
+    else if (!strcmp(name, "owner_cap")) s->force_cap = value == 1024 || value == 2048 || value == 8192 ? value : 0;
     else if (!strcmp(name, "overlap")) s->opt_overlap = value;
     else if (!strcmp(name, "fuse_fields")) s->opt_fuse_fields = value ? 1 : 0;
     else if (!strcmp(name, "verify")) s->opt_verify = value ? 1 : 0;
@@ -733,55 +627,48 @@ extern "C" int cafe_query_median_dev(cafe_sketch_t *s, const int32_t *d_ids, int
 
 extern "C" int cafe_insert_dev(cafe_sketch_t *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins,
                                cafe_stream_t stream) {
-    return insert_dev_on(s, d_ids, d_scores, n, d_ins, (hipStream_t)stream, (hipStream_t)stream);
+    return insert_dev_on(s, d_ids, d_scores, nullptr, 0, n, d_ins, nullptr, (hipStream_t)stream, (hipStream_t)stream);
 }
 
 // ---- real_n as the host knows it ------------------------------------------------------------------
 // sketch.cpp:291 needs real_n at the start of every call.  The value lives on the device; the kernel that closes an
-// insert leaves a tagged snapshot in pinned memory, which the host reads lagging.  Bound = newest snapshot + an
-// estimate of the growth of the calls issued since: crossings (or pops, whichever is larger) per inserted id, 8 x the
-// largest rate of the last 32 snapshots seen, + 64 (every id counts until 32 snapshots have been seen; option "exact_reset" keeps it that way).
-// Only when the bound passes 1.2 lim does the host wait for the exact value.  The closing kernel checks every
-// boundary against the real value and counts the ones the host got wrong (DevState::cadence_miss, counter [6]).
+// insert leaves a tagged snapshot in pinned memory.  Upper bound = newest snapshot + the ids of the calls issued since
+// (every inserted id raises real_n by at most one); only when that bound passes 1.2 lim does the host wait for the
+// exact value, so the decision is never an estimate.  cafe_backward_update_dev waits for every step's verdict anyway,
+// which keeps the snapshot current.
 static void read_mirror(cafe_sketch *s, Mirror *out) {
+    // the device writes the payload, a system-scope fence, then seq: a snapshot is consistent when seq reads the same
+    // before and after the payload
     const volatile uint32_t *src = reinterpret_cast<const volatile uint32_t *>(s->h_pinned);
-    uint32_t a[sizeof(Mirror) / 4], b[sizeof(Mirror) / 4];
-    for (int tries = 0; tries < 16; ++tries) {
+    const volatile uint32_t *seqp = &reinterpret_cast<const volatile Mirror *>(s->h_pinned)->seq;
+    uint32_t a[sizeof(Mirror) / 4];
+    for (int tries = 0; tries < 64; ++tries) {
+        const uint32_t s0 = *seqp;
+        __sync_synchronize();
         for (size_t i = 0; i < sizeof(Mirror) / 4; ++i) a[i] = src[i];
-        for (size_t i = 0; i < sizeof(Mirror) / 4; ++i) b[i] = src[i];
-        if (!memcmp(a, b, sizeof(a))) break;
+        __sync_synchronize();
+        if (*seqp == s0 && reinterpret_cast<Mirror *>(a)->seq == s0) break;
     }
-    memcpy(out, b, sizeof(Mirror));
+    memcpy(out, a, sizeof(Mirror));
 }
 
-long long cafe::growth_estimate(const cafe_sketch *s, long long n) {
-    if (s->opt_exact_reset) return n;
-    double rate = 0.0;
-    for (double r : s->rates) rate = std::max(rate, r);
-    const long long e = (long long)(8.0 * rate * (double)n) + 64;
-    return std::min(n, e);
+static void take_snapshot(cafe_sketch *s, const Mirror &m) {
+    s->base_real_n = m.st.real_n;
+    s->base_seq = m.seq;
+    s->fifo_hint = m.st.fifo_len;
+    if (s->thr_dirty_seq && (int32_t)(m.seq - s->thr_dirty_seq) >= 0) {
+        s->host_thr = m.st.thr;         // the snapshot is behind the reset (and every flip) that made it unknown
+        s->thr_dirty_seq = 0;
+    }
 }
 
 long long cafe::real_n_bound(cafe_sketch *s) {
     Mirror m;
     read_mirror(s, &m);
+    if (m.seq != 0 && (int32_t)(m.seq - s->base_seq) > 0 && (int32_t)(s->call_seq - m.seq) >= 0) take_snapshot(s, m);
+    if (s->call_seq - s->base_seq > 64u) return (long long)1 << 60;        // issued calls no longer in the ring
     long long ub = s->base_real_n;
-    uint32_t from = s->base_seq;
-    if (s->thr_dirty_seq && m.seq != 0 && (int32_t)(m.seq - s->thr_dirty_seq) >= 0 && (int32_t)(s->call_seq - m.seq) >= 0) {
-        s->host_thr = m.st.thr;         // the snapshot is behind the reset (and every flip) that made it unknown
-        s->thr_dirty_seq = 0;
-    }
-    if ((int32_t)(m.seq - s->base_seq) > 0 && (int32_t)(s->call_seq - m.seq) >= 0) {      // newer than the base
-        ub = m.st.real_n;
-        from = m.seq;
-        s->fifo_hint = m.st.fifo_len;
-        if (m.seq != s->rate_seen_seq && m.n > 0) {
-            s->rates[s->rate_pos++ & 31] = (double)std::max(m.cross, m.pops) / (double)m.n;
-            s->rate_seen_seq = m.seq;
-        }
-    }
-    if (s->call_seq - from > 64u) return (long long)1 << 60;        // issued calls no longer in the ring
-    for (uint32_t q = from + 1; (int32_t)(s->call_seq - q) >= 0; ++q) ub += growth_estimate(s, s->issued[q & 63].n);
+    for (uint32_t q = s->base_seq + 1; (int32_t)(s->call_seq - q) >= 0; ++q) ub += s->issued[q & 63].n;
     return ub;
 }
 
@@ -792,79 +679,68 @@ bool cafe::threshold_known_above_one(cafe_sketch *s) {
     return s->thr_dirty_seq == 0 && s->host_thr > 1.0f;
 }
 
+// waits for the insert issued last; afterwards the snapshot in pinned memory is that call's
+static int wait_last(cafe_sketch *s, Mirror *m) {
+    if (s->ev_done_valid) CAFE_HIP_CHECK(hipEventSynchronize(s->ev_done));
+    else CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));
+    read_mirror(s, m);
+    if (m->seq != s->call_seq) { set_error("internal: state snapshot %u does not belong to call %u", m->seq, s->call_seq); return 1; }
+    take_snapshot(s, *m);
+    s->counters[7]++;
+    return 0;
+}
+
 // the exact value: waits for the last insert's snapshot
 int cafe::real_n_exact(cafe_sketch *s, long long *out) {
     if (s->call_seq != s->base_seq) {
-        CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));
         Mirror m;
-        read_mirror(s, &m);
-        if (m.seq != s->call_seq) { set_error("internal: state snapshot %u does not belong to call %u", m.seq, s->call_seq); return 1; }
-        if (s->thr_dirty_seq) { s->host_thr = m.st.thr; s->thr_dirty_seq = 0; }
-        if (m.n > 0 && m.seq != s->rate_seen_seq) {
-            s->rates[s->rate_pos++ & 31] = (double)std::max(m.cross, m.pops) / (double)m.n;
-            s->rate_seen_seq = m.seq;
-        }
-        s->fifo_hint = m.st.fifo_len;
-        s->base_real_n = m.st.real_n;
-        s->base_seq = s->call_seq;
-        s->counters[7]++;
+        if (wait_last(s, &m)) return 1;
     }
     *out = s->base_real_n;
     return 0;
 }
 
-// waits for the insert issued last and tells whether the device rejected it (verify mode)
-int cafe::last_insert_rejected(cafe_sketch *s, bool *rejected) {
-    CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));
+// waits for the insert issued last and tells whether the device rejected it (verify mode), and why
+int cafe::last_insert_verdict(cafe_sketch *s, bool *rejected, int *reason) {
     Mirror m;
-    read_mirror(s, &m);
-    if (m.seq != s->call_seq) { set_error("internal: state snapshot %u does not belong to call %u", m.seq, s->call_seq); return 1; }
+    if (wait_last(s, &m)) return 1;
     *rejected = m.rejected != 0;
-    // either way the snapshot holds the exact scalars behind every call issued so far (a rejected call changes none)
-    if (!*rejected && m.n > 0 && m.seq != s->rate_seen_seq) {
-        s->rates[s->rate_pos++ & 31] = (double)std::max(m.cross, m.pops) / (double)m.n;
-        s->rate_seen_seq = m.seq;
-    }
-    s->base_real_n = m.st.real_n;
-    s->base_seq = s->call_seq;
-    s->fifo_hint = m.st.fifo_len;
-    if (s->thr_dirty_seq) { s->host_thr = m.st.thr; s->thr_dirty_seq = 0; }
+    *reason = (int)m.reason;
     if (*rejected) s->counters[1]--;        // it was counted as a call finished by the parallel path
-    s->counters[7]++;
     return 0;
 }
 
-int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st,
-                        hipStream_t pre) {
+int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const float *d_psum, int nparts, int n,
+                        int32_t *d_ins, float *d_scores_out, hipStream_t st, hipStream_t pre) {
     if (n < 0) { set_error("cafe_insert_dev: negative length"); return 1; }
     // sketch.cpp:282-289
     s->batch_num++;
     s->decay *= s->alpha;
     int flip_now = 0;
     if (s->decay > kDecayV) { s->decay /= kDecayV; s->flip ^= 1; flip_now = 1; }
-    if (flip_now) {                              // k_prologue: thr = (float)((double)thr / V)
+    if (flip_now) {                              // thr = (float)((double)thr / V)
         if (s->thr_dirty_seq) s->thr_dirty_seq = s->call_seq + 1;
         else s->host_thr = (float)((double)s->host_thr / kDecayV);
     }
-    // a call that stands for several reference calls (one per seg_len ids): the caller made sure that no flip and no
-    // reset falls on an inner boundary, so the remaining calls only advance the counters
+    // a call that stands for several reference calls (one per seg_len ids): the caller made sure that no flip falls on
+    // an inner boundary (the device checks the reset boundaries), so the remaining calls only advance the counters
     if (s->seg_len > 0 && n > 0)
         for (int k = 1; k < (n + s->seg_len - 1) / s->seg_len; ++k) { s->batch_num++; s->decay *= s->alpha; }
-    const bool parallel = !s->opt_serial && n > 0;
-    uint32_t *zero = nullptr;
-    int zero_words = 0;
-    if (parallel && par_prepare(s, n, &zero, &zero_words)) return 1;
-    if (!parallel && pre != st) {           // in-order kernel: nothing to run beside the scores
+    const bool parallel = !s->opt_serial && n > 0 && n <= kParMaxIds;
+    if (parallel && par_prepare(s, n)) return 1;
+    if (pre != st && !parallel) {           // nothing to run beside the scores
         CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, pre));
         CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));
         pre = st;
     }
-    hipLaunchKernelGGL(k_prologue, dim3(1), dim3(1024), 0, pre, s->d_state, flip_now, s->flip, zero, zero_words);
     // sketch.cpp:291
     if (s->adjust && (double)real_n_bound(s) > s->lim * 1.2) {
         long long exact;
-        if (real_n_exact(s, &exact)) return 1;          // rare: only when a reset may be due
+        if (real_n_exact(s, &exact)) return 1;          // only when a reset may be due
         if ((double)exact > s->lim * 1.2) {
+            // the reference flips first (sketch.cpp:284-289), then resets (:291): the scalars go in ahead of the reset
+            hipLaunchKernelGGL(k_prologue, dim3(1), dim3(64), 0, pre, s->d_state, flip_now, s->flip);
+            flip_now = 0;
             if (run_reset(s, pre)) return 1;
             s->base_real_n = s->lim;                     // sketch.cpp:113
             s->base_seq = s->call_seq;
@@ -873,17 +749,29 @@ int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_sco
         }
     }
     s->counters[0]++;
-    if (n == 0) return 0;
+    if (n == 0) {
+        hipLaunchKernelGGL(k_prologue, dim3(1), dim3(64), 0, pre, s->d_state, flip_now, s->flip);
+        if (pre != st) {
+            CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, pre));
+            CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));
+        }
+        return 0;
+    }
     s->call_seq++;
     s->issued[s->call_seq & 63] = {s->call_seq, n};
     int rc;
-    if (s->opt_serial) {
-        rc = launch_serial_insert(s, d_ids, d_scores, n, d_ins, 0, st);
+    if (!parallel) {
+        hipLaunchKernelGGL(k_prologue, dim3(1), dim3(64), 0, st, s->d_state, flip_now, s->flip);
+        rc = launch_serial_insert(s, d_ids, d_vals, n, d_ins, st);
         s->counters[2]++;
     } else {
-        rc = par_insert(s, d_ids, d_scores, n, d_ins, st, pre);
+        rc = par_insert(s, d_ids, d_vals, d_psum, nparts, n, d_ins, d_scores_out, flip_now, st, pre);
     }
-    if (rc == 0) s->last_stream = st;       // the closing kernel mirrors the device state into pinned host memory
+    if (rc == 0) {
+        s->last_stream = st;       // the closing kernel mirrors the device state into pinned host memory
+        CAFE_HIP_CHECK(hipEventRecord(s->ev_done, st));
+        s->ev_done_valid = 1;
+    }
     return rc;
 }
 

@@ -12,7 +12,7 @@ eng = CafeEmbeddingCollection(wl.counts, D, wl.hotn, wl.hash_sizes, wl.offsets, 
 ids = [torch.from_numpy(x).cuda() for x in wl.make_ids(123, steps=8)]
 grad = torch.randn(F, B, D, device="cuda")
 for i in range(60):
-    eng.forward(ids[i % 8]); eng.backward_update(grad, 0.1, per_field_calls=False)
+    eng.forward(ids[i % 8]); eng.backward_update(grad, 0.1, per_field_calls=True)
 torch.cuda.synchronize()
 L = eng.L
 buf = np.zeros(2 * 8192 * 8, np.uint64)
