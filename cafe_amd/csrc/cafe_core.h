@@ -341,6 +341,17 @@ struct ScoreSrc {
     }
 };
 
+// Sum of one field's partial sums (<= 64 of them), formed by the 64 lanes of a wave in a fixed tree order: every kernel
+// that needs a field's sum forms it this way, so they all see the same float.  All lanes of the wave must call it.
+constexpr int kMaxNormParts = 64;
+__device__ inline float field_sum_tree(const float *__restrict__ psum, int nparts, int f, bool live) {
+    const int j = threadIdx.x & 63;
+    float v = (live && j < nparts) ? psum[(size_t)f * nparts + j] : 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 __device__ inline int serial_insert_range(MainBucket *mt, LruBucket *lt, int n1, int n2, float thr, uint32_t gflip, SerialCtx &ctx,
                                           const int32_t *__restrict__ ids, const ScoreSrc &sc, int n, int32_t *__restrict__ ins,
                                           int seg, double reset_at) {

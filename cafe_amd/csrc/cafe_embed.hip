@@ -17,9 +17,9 @@ using namespace cafe;
 // the symbol, never a device address: host code uses the per-device pointer hipGetSymbolAddress returned.
 // ------------------------------------------------------------------------------------------------
 constexpr int kNoAllocMaxLookups = 1 << 20;
-constexpr int kNoAllocMaxFields = 128;        // x 32 partial sums per field behind the norms
+constexpr int kNoAllocMaxFields = 128;        // x 64 partial sums per field behind the norms
 constexpr int kNoAllocMaxDevices = 64;
-static __device__ __align__(256) float g_noalloc_scratch[kNoAllocMaxLookups + kNoAllocMaxFields * 32];
+static __device__ __align__(256) float g_noalloc_scratch[kNoAllocMaxLookups + kNoAllocMaxFields * 64];
 static float *g_noalloc_ptr[kNoAllocMaxDevices];      // [device] -> address of that device's copy, nullptr = not looked up
 
 // once per device, with that device current (called from cafe_tables_create)
@@ -192,6 +192,22 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     const int lpg = lanes_per_row(t->dim);
     const int blocks = (int)std::min<long>(((long)total + 255) / 256, 256 * 16);      // a wave per 64 lookups
     FastMod fm1 = make_fastmod(s->n1);
+    // Training steps: the plan of the insert that will follow (it reads the ids and the same pre-batch tables the gather
+    // reads) runs beside the gather on the sketch's second stream, behind everything queued on `st` so far.  Stopped
+    // when forwards come without updates (inference), resumed by the next cafe_backward_update_dev.
+    bool plan = false;
+    if (d_local_ids && s->opt_plan_ahead && s->opt_overlap && !s->opt_serial && s->opt_fuse_fields && s->side_stream &&
+        s->side_stream != st && total >= 32768 && total <= cafe::kParMaxIds && t->num_fields <= kMaxSeg) {
+        if (s->plan_valid) s->unused_plans++;
+        s->plan_valid = 0;
+        const bool reset_due = s->adjust && (double)cafe::real_n_bound(s) > s->lim * 1.2;
+        if (s->unused_plans < 2 && !reset_due) {
+            if (cafe::par_prepare(s, total)) return 1;
+            CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, st));
+            CAFE_HIP_CHECK(hipStreamWaitEvent(s->side_stream, s->ev_head_fork, 0));
+            plan = true;
+        }
+    }
 #define CAFE_FWD(L)                                                                                              \
     hipLaunchKernelGGL((k_forward<L, false>), dim3(blocks), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold, \
                        t->d_id_offset, t->d_hash_size, d_local_ids, d_in_gids, d_fields, batch, total, t->dim, d_gids, d_que, \
@@ -209,6 +225,9 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
 #undef CAFE_FWD
     if (t->timing) (void)hipEventRecord(t->ev_t[0][1], st);
     CAFE_HIP_CHECK(hipGetLastError());
+    if (plan) {
+        if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream)) return 1;
+    }
     return 0;
 }
 
@@ -258,13 +277,11 @@ extern "C" int cafe_forward_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const in
 // scores: sk_embedding_bag.py:178-189, intended semantics: the L2 norm of each lookup's own
 // output-gradient row, scaled per field so that scores average 1.
 // One pass over the gradient: a workgroup takes a contiguous run of one field's rows, writes their norms and the
-// run's partial sum; a field's sum is the sum of its <= 32 partials in run order, formed where it is needed (the
+// run's partial sum; a field's sum is the tree sum of its <= 64 partials (cafe_core.h::field_sum_tree), formed where it is needed (the
 // insert's owners, k_scale) -- always the same floats, no second pass over the norms and no extra launch.
 // ------------------------------------------------------------------------------------------------
-constexpr int kMaxNormParts = 32;
-
 static void norm_geometry(int batch, int *nparts, int *rows) {
-    int np = std::min(std::max((batch + 255) / 256, 1), kMaxNormParts);
+    int np = std::min(std::max((batch + 127) / 128, 1), kMaxNormParts);
     *rows = (batch + np - 1) / np;
     *nparts = (batch + *rows - 1) / *rows;
 }
@@ -280,22 +297,37 @@ __global__ void __launch_bounds__(256) k_grad_norm(const float *__restrict__ g, 
     const int r0 = part * rows, r1 = min(r0 + rows, batch);
     const size_t fbase = (size_t)f * batch;
     float run = 0.f;
-    // four rows per step and group: their loads are independent
-    for (int r = r0 + grp; r < r1; r += 4 * G) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // eight rows per step and group; rows past the end are loaded again from the last row and not counted, so that
+    // the loads of a step carry no condition and are all in flight together
+    constexpr int U = 8;
+    for (int r = r0 + grp; r < r1; r += U * G) {
+        float acc[U];
+        float4 v[U];
+        if (dim4 <= LPG) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int rr = r + u * G;
-            if (rr < r1) {
+            for (int u = 0; u < U; ++u) {
+                const int rr = min(r + u * G, r1 - 1);
+                v[u] = lig < dim4 ? reinterpret_cast<const float4 *>(g + (fbase + rr) * dim)[lig] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[u] = 0.f;
+                acc[u] += v[u].x * v[u].x; acc[u] += v[u].y * v[u].y; acc[u] += v[u].z * v[u].z; acc[u] += v[u].w * v[u].w;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rr = min(r + u * G, r1 - 1);
                 const float4 *row = reinterpret_cast<const float4 *>(g + (fbase + rr) * dim);
+                acc[u] = 0.f;
                 for (int c = lig; c < dim4; c += LPG) {
-                    const float4 v = row[c];
-                    acc[u] += v.x * v.x; acc[u] += v.y * v.y; acc[u] += v.z * v.z; acc[u] += v.w * v.w;
+                    const float4 w = row[c];
+                    acc[u] += w.x * w.x; acc[u] += w.y * w.y; acc[u] += w.z * w.z; acc[u] += w.w * w.w;
                 }
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int o = LPG >> 1; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, LPG);
             const int rr = r + u * G;
@@ -316,21 +348,35 @@ __global__ void __launch_bounds__(256) k_grad_norm(const float *__restrict__ g, 
     }
 }
 
-// s_i = gn_i * batch / sum (the expression of cafe_core.h::ScoreSrc); sums[f] on request
+// s_i = gn_i * batch / sum (the expression of cafe_core.h::ScoreSrc, the sum formed by field_sum_tree); sums[f] on
+// request.  A workgroup covers 256 consecutive lookups, i.e. one or two fields at the usual batch sizes.
 __global__ void __launch_bounds__(256) k_scale(const float *__restrict__ gn, const float *__restrict__ psum, int nparts,
                                                int batch, int total, float *__restrict__ scores, float *__restrict__ sums,
                                                int num_fields) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sums && i < num_fields) {
-        float acc = 0.f;
-        for (int j = 0; j < nparts; ++j) acc += psum[(size_t)i * nparts + j];
-        sums[i] = acc;
+    __shared__ float fs[4];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * 256, i = i0 + tid;
+    const int f_lo = min(i0, max(total - 1, 0)) / batch, f_hi = min(i0 + 255, max(total - 1, 0)) / batch;
+    float mine = 0.f;
+    const int f_me = i < total ? i / batch : -1;
+    for (int base = f_lo; base <= f_hi; base += 4) {
+        const int f = base + (tid >> 6);
+        const float v = field_sum_tree(psum, nparts, f, f <= f_hi);
+        __syncthreads();
+        if (f <= f_hi && (tid & 63) == 0) fs[tid >> 6] = v;
+        __syncthreads();
+        if (f_me >= base && f_me < base + 4) mine = fs[f_me - base];
     }
-    if (!scores || i >= total) return;
-    const int f = i / batch;
-    float acc = 0.f;
-    for (int j = 0; j < nparts; ++j) acc += psum[(size_t)f * nparts + j];
-    scores[i] = gn[i] * (float)batch / acc;
+    if (sums) {
+        // field sums for the caller: workgroup 0 walks all fields
+        if (blockIdx.x == 0)
+            for (int base = 0; base < num_fields; base += 4) {
+                const int f = base + (tid >> 6);
+                const float v = field_sum_tree(psum, nparts, f, f < num_fields);
+                if (f < num_fields && (tid & 63) == 0) sums[f] = v;
+            }
+    }
+    if (scores && i < total) scores[i] = gn[i] * (float)batch / mine;
 }
 
 // norms and partial sums of one step: gn [F * batch], psum [F * nparts]
@@ -362,7 +408,7 @@ static int scores_common(cafe_tables_t *t, const float *d_grad_out, int batch, f
     if (total <= 0) return 0;
     int nparts;
     if (norms_common(t, d_grad_out, batch, gn, psum, &nparts, st)) return 1;
-    hipLaunchKernelGGL(k_scale, dim3((std::max(total, t->num_fields) + 255) / 256), dim3(256), 0, st, gn, psum, nparts, batch,
+    hipLaunchKernelGGL(k_scale, dim3((total + 255) / 256), dim3(256), 0, st, gn, psum, nparts, batch,
                        total, d_scores, d_sums, t->num_fields);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
@@ -928,9 +974,11 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             s->seg_len = cadence ? batch : 0;
             s->score_seg = batch;
             s->verify_mode = 1;
+            s->plan_expect = d_local_ids;
+            s->unused_plans = 0;
             if (t->timing) s->ev_chain[0] = t->ev_t[2][0], s->ev_chain[1] = t->ev_t[2][1];
             const int rc = cafe::insert_dev_on(s, d_gids, gn, psum, nparts, total, d_ins, d_scores, st, (s->opt_overlap & 1) ? side : st);
-            s->seg_len = 0; s->score_seg = 0; s->verify_mode = 0;
+            s->seg_len = 0; s->score_seg = 0; s->verify_mode = 0; s->plan_expect = nullptr;
             s->ev_chain[0] = s->ev_chain[1] = nullptr;
             if (rc) return 1;
             if (side != st && !plan_done) {

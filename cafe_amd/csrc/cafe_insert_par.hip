@@ -88,6 +88,7 @@ struct Ctl {                // zeroed by k_offsets at the start of every call
     uint32_t ngot;          // entries of the got list
     uint32_t nclassc;       // class C items (diagnostics)
     uint32_t ticket_off, ticket_commit;
+    uint32_t ticket_sub[32 * 16];   // first level of the commit ticket, one counter per 64-byte line
     uint32_t bar_count, bar_gen;
     uint32_t pad;
 };
@@ -117,6 +118,7 @@ struct Geo {
                                 // applied, the host issues it again) instead of going to the in-order loop
     int sseg;                   // > 0: ids per field for the score scaling (Score::psum)
     int nparts;                 // partial sums per field behind Score::psum
+    int prof;                   // diagnostic builds: stamp slot of the kernel
     FastMod fm1, fm2;
 };
 
@@ -137,6 +139,18 @@ struct __attribute__((aligned(16))) Rec {
     uint32_t pad;
 };
 
+// where the ids come from: global ids, or the caller's per-field ids with the fields' offsets (sk_embedding_bag.py:103),
+// so that the plan can run beside the forward kernel that writes the global ids
+struct IdSrc {
+    const int32_t *gids;
+    const int64_t *local_ids;
+    const int64_t *id_offset;
+    int batch;
+    __device__ uint32_t at(int i) const {
+        return local_ids ? (uint32_t)(int32_t)(local_ids[i] + id_offset[i / batch]) : (uint32_t)gids[i];
+    }
+};
+
 // where the scores come from: explicit values, or per-lookup norms with per-field partial sums (the scaling of
 // sk_embedding_bag.py:189 is then applied where a score is consumed)
 struct Score {
@@ -147,13 +161,14 @@ struct Score {
 // Diagnostic build (make EXTRA=-DCAFE_PROF): wave 0 of every round-1 workgroup stamps the 100 MHz wall clock at phase
 // boundaries; tools/diag_stamps.py reads them back.  No code in the normal build.
 #ifdef CAFE_PROF
-__device__ unsigned long long g_dbg[8192 * 8];
-#define CAFE_STAMP(k) do { if (threadIdx.x == 0) g_dbg[(blockIdx.x & 8191) * 8 + (k)] = wall_clock64(); } while (0)
-#define CAFE_STAMP_VAL(k, v) do { if (threadIdx.x == 0) g_dbg[(blockIdx.x & 8191) * 8 + (k)] = (v); } while (0)
+constexpr int kProfSlots = 8, kProfBlocks = 4096;
+__device__ unsigned long long g_dbg[kProfSlots][kProfBlocks][8];
+#define CAFE_STAMP(slot, k) do { if (threadIdx.x == 0) g_dbg[slot][blockIdx.x & (kProfBlocks - 1)][k] = wall_clock64(); } while (0)
+#define CAFE_STAMP_VAL(slot, k, v) do { if (threadIdx.x == 0) g_dbg[slot][blockIdx.x & (kProfBlocks - 1)][k] = (v); } while (0)
 extern "C" int cafe_debug_read(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(g_dbg)) != hipSuccess; }
 #else
-#define CAFE_STAMP(k) do { } while (0)
-#define CAFE_STAMP_VAL(k, v) do { } while (0)
+#define CAFE_STAMP(slot, k) do { } while (0)
+#define CAFE_STAMP_VAL(slot, k, v) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -174,25 +189,9 @@ __device__ inline unsigned long long lanes_below() { return (1ull << (threadIdx.
 // ------------------------------------------------------------------------------------------------
 // plan: classify and rank (stable multi-split), offsets, scatter
 // ------------------------------------------------------------------------------------------------
-// first slot holding x (-1: none) and whether that slot is hot; `pending`: the bucket's lazy decay is due
-__device__ inline int probe_class(const MainBucket *__restrict__ mt, int h1, uint32_t x, uint32_t gflip, bool &hot, bool &pending) {
-    const int4 *p = reinterpret_cast<const int4 *>(&mt[h1]);
-    const int4 v = p[0], d = p[1];
-    const uint32_t flip = mt[h1].flip;
-    // the reference stops at the first slot holding the id (sketch.cpp:214-215): a hot copy behind a cold one is not hit
-    int first = -1, dic = 0;
-    if ((uint32_t)v.w == x) { first = 3; dic = d.w; }
-    if ((uint32_t)v.z == x) { first = 2; dic = d.z; }
-    if ((uint32_t)v.y == x) { first = 1; dic = d.y; }
-    if ((uint32_t)v.x == x) { first = 0; dic = d.x; }
-    pending = flip != gflip;
-    hot = first >= 0 && dic != 0;
-    return first;
-}
-
 // plan word A: bits 0-10 rank inside (chunk, bin), 11-23 bin, 24-25 slot (hot), 26 presumed miss; word B (LRU list):
 // bits 0-10 rank, 11-23 bin
-__global__ void __launch_bounds__(kPlanThreads) k_assign(Geo g, const MainBucket *__restrict__ mt, const int32_t *__restrict__ ids,
+__global__ void __launch_bounds__(kPlanThreads) k_assign(Geo g, const MainBucket *__restrict__ mt, IdSrc ids,
                                                          uint16_t *__restrict__ cm /* [nchunks][nbins] */,
                                                          uint32_t *__restrict__ planA, uint32_t *__restrict__ planB) {
     extern __shared__ uint16_t wh[];            // [kPlanWaves][nbins]
@@ -205,6 +204,22 @@ __global__ void __launch_bounds__(kPlanThreads) k_assign(Geo g, const MainBucket
     const unsigned long long below = lanes_below();
     uint32_t wa[kPlanRows], wb[kPlanRows];
     const int base = blockIdx.x * kChunk + wave * (kChunk / kPlanWaves);
+    // the ids of all rows, then the probes of all rows, are requested before anything is looked at: two memory round
+    // trips per wave instead of two per row
+    uint32_t xs[kPlanRows], fl[kPlanRows];
+    int b1s[kPlanRows];
+    int4 vs[kPlanRows], ds[kPlanRows];
+#pragma unroll
+    for (int r = 0; r < kPlanRows; ++r) {
+        const int i = base + r * 64 + lane;
+        xs[r] = i < g.n ? ids.at(i) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < kPlanRows; ++r) {
+        b1s[r] = fast_hash(xs[r], g.fm1);
+        const int4 *p = reinterpret_cast<const int4 *>(&mt[b1s[r]]);
+        vs[r] = p[0]; ds[r] = p[1]; fl[r] = mt[b1s[r]].flip;
+    }
 #pragma unroll
     for (int r = 0; r < kPlanRows; ++r) {
         const int i = base + r * 64 + lane;
@@ -212,10 +227,16 @@ __global__ void __launch_bounds__(kPlanThreads) k_assign(Geo g, const MainBucket
         uint32_t binA = 0, binB = 0, extra = 0;
         bool has_b = false;
         if (valid) {
-            const uint32_t x = (uint32_t)ids[i];
-            const int b1 = fast_hash(x, g.fm1);
-            bool hot, pending;
-            const int slot = probe_class(mt, b1, x, g.gflip, hot, pending);
+            const uint32_t x = xs[r];
+            const int b1 = b1s[r];
+            // the reference stops at the first slot holding the id (sketch.cpp:214-215): a hot copy behind a cold one is not hit
+            int slot = -1, dic = 0;
+            if ((uint32_t)vs[r].w == x) { slot = 3; dic = ds[r].w; }
+            if ((uint32_t)vs[r].z == x) { slot = 2; dic = ds[r].z; }
+            if ((uint32_t)vs[r].y == x) { slot = 1; dic = ds[r].y; }
+            if ((uint32_t)vs[r].x == x) { slot = 0; dic = ds[r].x; }
+            const bool pending = fl[r] != g.gflip;       // the bucket's lazy decay is due
+            const bool hot = slot >= 0 && dic != 0;
             const int p1 = b1 / g.bpp1;
             if (g.hot && hot && !pending) {
                 binA = (uint32_t)(bin_hot0(g) + p1);
@@ -265,24 +286,49 @@ __global__ void __launch_bounds__(kPlanThreads) k_assign(Geo g, const MainBucket
     }
 }
 
-// Column prefix sums over the chunks (one lane per bin); the workgroup that finishes last turns the bin totals into
-// partition offsets, zeroes the control block and applies the per-call scalars of sketch.cpp:282-289 (the flip
-// decision is the host's: it depends on the call count only).
+// Column prefix sums over the chunks: a workgroup takes 32 bins, eight lanes share a bin's column.  The workgroup that
+// finishes last turns the bin totals into partition offsets, zeroes the control block and applies the per-call scalars
+// of sketch.cpp:282-289 (the flip decision is the host's: it depends on the call count only).
+constexpr int kOffBins = 32, kOffParts = kThreads / kOffBins;
 __global__ void __launch_bounds__(kThreads) k_offsets(Geo g, const uint16_t *__restrict__ cm, uint32_t *__restrict__ colpref,
                                                       uint32_t *__restrict__ tot, uint32_t *__restrict__ off, Ctl *ctl,
                                                       uint32_t *__restrict__ evcnt, DevState *st) {
     __shared__ uint32_t sh[kThreads];
     __shared__ uint32_t carry, last;
     const int tid = threadIdx.x;
-    const int b = blockIdx.x * kThreads + tid;
-    if (b < g.nbins) {
-        uint32_t run = 0;
-        for (int c = 0; c < g.nchunks; ++c) {
-            const uint32_t v = cm[(size_t)c * g.nbins + b];
-            colpref[(size_t)c * g.nbins + b] = run;
-            run += v;
+    CAFE_STAMP(3, 0);
+    {
+        const int b = blockIdx.x * kOffBins + (tid & (kOffBins - 1)), part = tid / kOffBins;
+        const int cpp = (g.nchunks + kOffParts - 1) / kOffParts;
+        const int c0 = part * cpp, c1 = min(c0 + cpp, g.nchunks);
+        const bool live = b < g.nbins;
+        const int bb = live ? b : 0;
+        uint32_t sum = 0;
+        for (int c = c0; c < c1; c += 8) {          // eight independent loads per step
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = cm[(size_t)min(c + u, g.nchunks - 1) * g.nbins + bb];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += (c + u < c1) ? v[u] : 0u;
         }
-        __hip_atomic_store(&tot[b], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh[tid] = live ? sum : 0u;
+        __syncthreads();
+        CAFE_STAMP(3, 1);
+        uint32_t run = 0, total = 0;
+        for (int k = 0; k < kOffParts; ++k) {
+            const uint32_t v = sh[k * kOffBins + (tid & (kOffBins - 1))];
+            if (k < part) run += v;
+            total += v;
+        }
+        for (int c = c0; c < c1; c += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = cm[(size_t)min(c + u, g.nchunks - 1) * g.nbins + bb];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (live && c + u < c1) { colpref[(size_t)(c + u) * g.nbins + b] = run; run += v[u]; }
+        }
+        if (live && part == 0) __hip_atomic_store(&tot[b], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -297,8 +343,10 @@ __global__ void __launch_bounds__(kThreads) k_offsets(Geo g, const uint16_t *__r
         }
     }
     __syncthreads();
+    CAFE_STAMP(3, 2);
     if (!last) return;
-    // three exclusive scans: main bins (C and M of a partition adjacent), LRU bins, hot bins
+    // three exclusive scans: main bins (C and M of a partition adjacent), LRU bins, hot bins.  A lane takes 16 consecutive
+    // bins; lane totals are scanned by shuffles, wave totals through LDS.
     uint32_t over = 0, maxpart = 0, maxhot = 0, nclassc = 0;
     for (int list = 0; list < 3; ++list) {
         const int b0 = list == 0 ? 0 : list == 1 ? bin_lru0(g) : bin_hot0(g);
@@ -306,35 +354,41 @@ __global__ void __launch_bounds__(kThreads) k_offsets(Geo g, const uint16_t *__r
         uint32_t *o = off + (list == 0 ? 0 : list == 1 ? off_lru0(g) : off_hot0(g));
         if (tid == 0) carry = 0;
         __syncthreads();
-        for (int base = 0; base < cnt; base += kThreads) {
-            const int i = base + tid;
-            const uint32_t v = i < cnt ? __hip_atomic_load(&tot[b0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            if (list == 0) {
-                // a main partition's size is C + M: pair sums via the neighbour lane
-                const uint32_t nbv = __shfl_xor(v, 1, 64);
-                if (!(i & 1)) { maxpart = max(maxpart, v + nbv); nclassc += v; }
-            } else if (list == 1) {
-                maxpart = max(maxpart, v);
-            } else {
-                maxhot = max(maxhot, v);
+        for (int base = 0; base < cnt; base += 16 * kThreads) {
+            uint32_t v[16], sum = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = base + tid * 16 + u;
+                v[u] = i < cnt ? __hip_atomic_load(&tot[b0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             }
-            sh[tid] = v;
-            __syncthreads();
-            for (int d = 1; d < kThreads; d <<= 1) {
-                const uint32_t add = tid >= d ? sh[tid - d] : 0u;
-                __syncthreads();
-                sh[tid] += add;
-                __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                sum += v[u];
+                if (list == 0) { if (u & 1) { maxpart = max(maxpart, v[u] + v[u - 1]); nclassc += v[u - 1]; } }
+                else if (list == 1) maxpart = max(maxpart, v[u]);
+                else maxhot = max(maxhot, v[u]);
             }
-            if (i < cnt) o[i] = carry + sh[tid] - v;
+            uint32_t inc = sum;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((tid & 63) >= d) inc += x; }
+            if ((tid & 63) == 63) sh[tid >> 6] = inc;
             __syncthreads();
-            if (tid == kThreads - 1) carry += sh[kThreads - 1];
+            uint32_t run = carry + inc - sum;
+            for (int w = 0; w < (tid >> 6); ++w) run += sh[w];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = base + tid * 16 + u;
+                if (i < cnt) o[i] = run;
+                run += v[u];
+            }
+            __syncthreads();
+            if (tid == kThreads - 1) carry = run;
             __syncthreads();
         }
         if (tid == 0) o[cnt] = carry;
         __syncthreads();
     }
     (void)over;
+    CAFE_STAMP(3, 3);
     // control block and move counters start at zero; the LRU clock placeholder clock0 + 1 + position must stay positive
     uint32_t *cw = reinterpret_cast<uint32_t *>(ctl);
     for (int i = tid; i < (int)kCtlWords; i += kThreads) cw[i] = 0;
@@ -357,15 +411,16 @@ __global__ void __launch_bounds__(kThreads) k_offsets(Geo g, const uint16_t *__r
         st->rounds = 0;
         if ((long long)st->clk + g.n + 2 >= 0x7fffffffLL) ctl->overflow = 1;
     }
+    CAFE_STAMP(3, 4);
 }
 
-__global__ void __launch_bounds__(256) k_scatter(Geo g, const int32_t *__restrict__ ids, const uint32_t *__restrict__ planA,
+__global__ void __launch_bounds__(256) k_scatter(Geo g, IdSrc ids, const uint32_t *__restrict__ planA,
                                                  const uint32_t *__restrict__ planB, const uint32_t *__restrict__ colpref,
                                                  const uint32_t *__restrict__ off, Rec *__restrict__ rec1, Rec *__restrict__ rec2,
                                                  Rec *__restrict__ rech, uint8_t *__restrict__ miss) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.n) return;
-    const uint32_t x = (uint32_t)ids[i];
+    const uint32_t x = ids.at(i);
     const uint32_t a = planA[i];
     const int chunk = i / kChunk;
     const int binA = (int)((a >> 11) & 0x1fffu);
@@ -397,65 +452,69 @@ __global__ void __launch_bounds__(256) k_scatter(Geo g, const int32_t *__restric
 // ------------------------------------------------------------------------------------------------
 // Sorted view of a partition (what the replay loops walk) and, aliased over it, the scratch of the sort that
 // produces it.  CAP elements.
-template <int CAP>
+template <int CAP, bool MOVES>
 struct Sorted {
     uint32_t sg[CAP];       // bucket index inside the partition (hot list: << 2 | slot)
     uint32_t stm[CAP];      // 2 * position (+ 1 for a move)
-    uint32_t px[CAP];       // id
+    uint32_t px[CAP];       // id (hot list: running score)
     float pc[CAP];          // score
-    uint16_t pm[CAP];       // moves: index into the move list | kind == 1 ? 0x8000 : 0
+    uint16_t pm[MOVES ? CAP : 2];       // moves: index into the move list | kind == 1 ? 0x8000 : 0
     uint8_t po[CAP];        // per-item flags / outcome
 };
-template <int CAP>
+template <int CAP, bool MOVES>
 struct SortTmp {
     uint32_t grp[CAP];      // sort key per element, in input order
-    uint32_t tpos[CAP];     // time per element, in input order (merge of the item lists with the move list)
+    uint32_t tpos[MOVES ? CAP : 2];     // time per element, in input order (merge of the item lists with the move list)
     uint16_t pa[CAP], pb[CAP], lr[CAP];
     uint16_t hist[kWaves][kDigits];
     uint32_t wtot[kWaves];
 };
-template <int CAP>
+template <int CAP, bool MOVES>
 union OwnerLds {
-    Sorted<CAP> s;
-    SortTmp<CAP> t;
+    Sorted<CAP, MOVES> s;
+    SortTmp<CAP, MOVES> t;
 };
 
 // Stable sort of n <= CAP elements by t.grp[element] (`bits` wide): LSD counting passes of kDigitBits bits.  Elements
 // are taken in the order t.pa[0 .. n) when `init`, else 0 .. n-1.  Each wave walks a contiguous range of the sequence row
 // by row; equal digits of a row are found by ballots, so ranks need no atomics and the order inside a digit is the
 // sequence order.  On return t.lr[element] is the element's slot.  All lanes of the workgroup call it.
-template <int CAP>
-__device__ inline void lsd_sort(SortTmp<CAP> &t, int n, int bits, bool init) {
+template <int CAP, bool MOVES>
+__device__ inline void lsd_sort(SortTmp<CAP, MOVES> &t, int n, int bits, bool init) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long below = lanes_below();
     const int rows = (n + 63) >> 6, rpw = (rows + kWaves - 1) / kWaves;
     const int r0 = wave * rpw, r1 = min(r0 + rpw, rows);
     uint16_t *pin = t.pa, *pout = t.pb;
     bool have = init;
-    int shift = 0;
-    do {
-        const int db = min(kDigitBits, max(bits - shift, 1));
-        for (int i = tid; i < kWaves * kDigits / 2; i += kThreads) reinterpret_cast<uint32_t *>(&t.hist[0][0])[i] = 0;
+    // the key bits are split evenly over the passes: 12 bits are two passes of 64 digits, not one of 1024 and one of 4
+    const int npass = max(1, (bits + kDigitBits - 1) / kDigitBits);
+    const int db = max(1, (bits + npass - 1) / npass), nd = 1 << db;
+    for (int pass = 0, shift = 0; pass < npass; ++pass, shift += db) {
+        for (int i = tid; i < kWaves * nd / 2; i += kThreads) reinterpret_cast<uint32_t *>(&t.hist[0][0])[i] = 0;     // hist as [kWaves][nd]
         __syncthreads();
+        uint16_t *hw = &t.hist[0][0] + wave * nd;
         for (int r = r0; r < r1; ++r) {
             const int j = r * 64 + lane;
             const bool valid = j < n;
             const int src = valid ? (have ? pin[j] : j) : 0;
-            const uint32_t d = valid ? (t.grp[src] >> shift) & (uint32_t)(kDigits - 1) : 0u;
+            const uint32_t d = valid ? (t.grp[src] >> shift) & (uint32_t)(nd - 1) : 0u;
             const unsigned long long m = match_any(d, db, valid);
             uint32_t old = 0;
-            if (valid && !(m & below)) { old = t.hist[wave][d]; t.hist[wave][d] = (uint16_t)(old + __popcll(m)); }
+            if (valid && !(m & below)) { old = hw[d]; hw[d] = (uint16_t)(old + __popcll(m)); }
             old = __shfl(old, m ? __builtin_ctzll(m) : 0, 64);
             if (valid) t.lr[j] = (uint16_t)(old + __popcll(m & below));
         }
         __syncthreads();
         {
-            // digits 4 tid .. 4 tid + 3: totals over the waves, exclusive scan over all digits, per-wave bases
-            uint32_t c[4][kWaves], sum = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int w = 0; w < kWaves; ++w) { c[k][w] = t.hist[w][4 * tid + k]; sum += c[k][w]; }
+            // a lane takes dpl consecutive digits: totals over the waves, exclusive scan over all digits, per-wave bases
+            const int dpl = max(1, nd / kThreads);
+            const int d0 = tid * dpl;
+            uint16_t *h0 = &t.hist[0][0];
+            uint32_t sum = 0;
+            if (d0 < nd)
+                for (int k = 0; k < dpl; ++k)
+                    for (int w = 0; w < kWaves; ++w) sum += h0[w * nd + d0 + k];
             uint32_t inc = sum;
             for (int o = 1; o < 64; o <<= 1) {
                 const uint32_t v = __shfl_up(inc, o, 64);
@@ -465,36 +524,48 @@ __device__ inline void lsd_sort(SortTmp<CAP> &t, int n, int bits, bool init) {
             __syncthreads();
             uint32_t run = inc - sum;
             for (int w = 0; w < wave; ++w) run += t.wtot[w];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int w = 0; w < kWaves; ++w) { t.hist[w][4 * tid + k] = (uint16_t)run; run += c[k][w]; }
+            if (d0 < nd)
+                for (int k = 0; k < dpl; ++k)
+                    for (int w = 0; w < kWaves; ++w) { const uint32_t c = h0[w * nd + d0 + k]; h0[w * nd + d0 + k] = (uint16_t)run; run += c; }
         }
         __syncthreads();
         for (int r = r0; r < r1; ++r) {
             const int j = r * 64 + lane;
             if (j >= n) continue;
             const int src = have ? pin[j] : j;
-            const uint32_t d = (t.grp[src] >> shift) & (uint32_t)(kDigits - 1);
-            pout[t.hist[wave][d] + t.lr[j]] = (uint16_t)src;
+            const uint32_t d = (t.grp[src] >> shift) & (uint32_t)(nd - 1);
+            pout[hw[d] + t.lr[j]] = (uint16_t)src;
         }
         __syncthreads();
         uint16_t *sw = pin; pin = pout; pout = sw;
         have = true;
-        shift += kDigitBits;
-    } while (shift < bits);
+    }
     for (int s = tid; s < n; s += kThreads) t.lr[pin[s]] = (uint16_t)s;
     __syncthreads();
 }
 
-// per-field sums of the norms from the partial sums, in a fixed order, into LDS (every workgroup gets the same floats)
+// per-field sums of the norms from the partial sums into LDS (every workgroup gets the same floats: field_sum_tree);
+// a wave per field
 __device__ inline void field_sums(const Geo &g, const Score &sc, float *fsum) {
     if (!sc.psum) return;
     const int F = (g.n + g.sseg - 1) / g.sseg;
-    for (int f = threadIdx.x; f < F; f += blockDim.x) {
-        float acc = 0.f;
-        for (int j = 0; j < g.nparts; ++j) acc += sc.psum[(size_t)f * g.nparts + j];
-        fsum[f] = acc;
+    const int per = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int kMaxIter = kMaxSeg / kWaves;      // workgroups have at least kWaves waves
+    float v[kMaxIter];
+    // every partial sum this lane contributes to is requested before the first tree runs: one memory round trip
+#pragma unroll
+    for (int k = 0; k < kMaxIter; ++k) {
+        const int f = k * per + wave;
+        v[k] = (f < F && lane < g.nparts) ? sc.psum[(size_t)f * g.nparts + lane] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxIter; ++k) {
+        const int f = k * per + wave;
+        if (k * per >= F) break;
+        float x = v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);        // cafe_core.h::field_sum_tree
+        if (f < F && lane == 0) fsum[f] = x;
     }
 }
 __device__ inline ScoreSrc score_src(const Geo &g, const Score &sc, const float *fsum) {
@@ -510,8 +581,8 @@ __device__ inline ScoreSrc score_src(const Geo &g, const Score &sc, const float 
 // [2 * position : 23][0 : 16], hrun (score of the slot after the item: what a move into the bucket later in the batch
 // has to see, sketch.cpp:244-247), and at the first item of every slot hfin = {bucket * 4 + slot, final score}
 // (-1 elsewhere), applied to the table by k_commit.
-template <int CAP>
-__device__ inline void hot_owner(OwnerLds<CAP> &L, int *heavy, int *n_heavy, float *fsum, const Geo &g, int p,
+template <int CAP, bool MV>
+__device__ inline void hot_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy, float *fsum, const Geo &g, int p,
                                  const MainBucket *__restrict__ mt, const DevState *__restrict__ st, Ctl *ctl,
                                  const uint32_t *__restrict__ off, const Rec *__restrict__ rech, const Score &sc,
                                  unsigned long long *__restrict__ hkey, float *__restrict__ hrun, int2 *__restrict__ hfin,
@@ -522,13 +593,16 @@ __device__ inline void hot_owner(OwnerLds<CAP> &L, int *heavy, int *n_heavy, flo
     if (total == 0) return;
     if (total > CAP) { if (tid == 0) ctl->overflow = 1; return; }
     if (tid == 0) *n_heavy = 0;
+    CAFE_STAMP_VAL(g.prof, 7, 1ull | ((unsigned long long)total << 8));
     field_sums(g, sc, fsum);
     const int b0 = p * g.bpp1;
     const Rec *recs = rech + o0;
     if (total > 512) __builtin_amdgcn_s_setprio(3);
     for (int j = tid; j < total; j += kThreads) L.t.grp[j] = recs[j].bl;
     __syncthreads();
-    lsd_sort<CAP>(L.t, total, g.bits1 + 2, false);
+    CAFE_STAMP(g.prof, 1);
+    lsd_sort<CAP, MV>(L.t, total, g.bits1 + 2, false);
+    CAFE_STAMP(g.prof, 2);
     constexpr int IPT = CAP / kThreads;
     uint16_t myr[IPT];
 #pragma unroll
@@ -545,28 +619,54 @@ __device__ inline void hot_owner(OwnerLds<CAP> &L, int *heavy, int *n_heavy, flo
         }
     }
     __syncthreads();
+    CAFE_STAMP(g.prof, 3);
     const float thr = st->thr;
     int2 *fin = hfin + o0;
-    // short runs: one lane each; long runs: a wave each, 64 items at a time
+    // the table's score of every slot that has items, requested together (a wave with several long runs would
+    // otherwise pay one memory round trip per run)
+    for (int s = tid; s < total; s += kThreads) {
+        const uint32_t bs = L.s.sg[s];
+        if (s == 0 || L.s.sg[s - 1] != bs) L.s.px[s] = __float_as_uint(mt[b0 + (int)(bs >> 2)].cnt[bs & 3u]);
+    }
+    __syncthreads();
+    // Ordered sums: the score of a slot after every one of its items, in batch order, left in px[] (the table's score at
+    // the head is read before it is overwritten).  Runs below 64 items: one lane each, four items per LDS round trip
+    // (po[e] says whether item e + 1 belongs to the same run).  Longer runs: a wave each -- every lane walks the same
+    // chain of adds, eight scores requested from LDS ahead of their use, so the chain runs at the latency of a float
+    // add per item.  Crossings (sketch.cpp:218-220) are evaluated afterwards for all items at once.
+    constexpr int kLongRun = 64;
+    for (int s = tid; s < total; s += kThreads) L.s.po[s] = (s + 1 < total && L.s.sg[s + 1] == L.s.sg[s]) ? 1 : 0;
+    for (int s = total + tid; s < min(total + 4, CAP); s += kThreads) L.s.po[s] = 0;
+    __syncthreads();
     for (int s = tid; s < total; s += kThreads) {
         const uint32_t bs = L.s.sg[s];
         const bool head = s == 0 || L.s.sg[s - 1] != bs;
         if (!head) { fin[s] = make_int2(-1, 0); continue; }
-        if (s + kHeavySeg <= total && L.s.sg[s + kHeavySeg - 1] == bs) {
+        if (s + kLongRun <= total && L.s.sg[s + kLongRun - 1] == bs) {
             const int at = atomicAdd(n_heavy, 1);
             if (at < kMaxHeavy) { heavy[at] = s; continue; }
         }
         const int bucket = b0 + (int)(bs >> 2), slot = (int)(bs & 3u);
-        float acc = mt[bucket].cnt[slot];
-        for (int e = s; e < total && L.s.sg[e] == bs; ++e) {
-            const float c = L.s.pc[e];
-            acc += c;
-            L.s.po[e] = (acc >= thr && acc - c < thr) ? oCross : 0;         // sketch.cpp:218-220
-            L.s.pc[e] = acc;
+        float acc = __uint_as_float(L.s.px[s]);
+        int e = s;
+        for (;;) {
+            // items e .. e + 3 (reads past the end of the run, or of the partition, are not used)
+            const float c0 = L.s.pc[e], c1 = L.s.pc[min(e + 1, CAP - 1)], c2 = L.s.pc[min(e + 2, CAP - 1)], c3 = L.s.pc[min(e + 3, CAP - 1)];
+            const uint8_t k0 = L.s.po[e], k1 = L.s.po[min(e + 1, CAP - 1)], k2 = L.s.po[min(e + 2, CAP - 1)], k3 = L.s.po[min(e + 3, CAP - 1)];
+            acc += c0; L.s.px[e] = __float_as_uint(acc);
+            if (!k0) break;
+            acc += c1; L.s.px[e + 1] = __float_as_uint(acc);
+            if (!k1) break;
+            acc += c2; L.s.px[e + 2] = __float_as_uint(acc);
+            if (!k2) break;
+            acc += c3; L.s.px[e + 3] = __float_as_uint(acc);
+            if (!k3) break;
+            e += 4;
         }
         fin[s] = make_int2(bucket * 4 + slot, __float_as_int(acc));
     }
     __syncthreads();
+    CAFE_STAMP(g.prof, 4);
     {
         const int lane = tid & 63, wave = tid >> 6;
         const int nh = min(*n_heavy, kMaxHeavy);
@@ -574,34 +674,55 @@ __device__ inline void hot_owner(OwnerLds<CAP> &L, int *heavy, int *n_heavy, flo
             const int s = heavy[h];
             const uint32_t bs = L.s.sg[s];
             const int bucket = b0 + (int)(bs >> 2), slot = (int)(bs & 3u);
-            float acc = mt[bucket].cnt[slot];
-            for (int e = s;; e += 64) {
-                const int idx = e + lane;
-                const bool act = idx < total && L.s.sg[idx] == bs;
-                const unsigned long long m = __ballot(act);
-                if (!m) break;
-                const int r = __popcll(m);                    // the run's items are contiguous from lane 0
-                const float c = act ? L.s.pc[idx] : 0.0f;
-                float mine = 0.0f;
-                for (int j = 0; j < r; ++j) {
-                    acc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), j));
-                    mine = lane == j ? acc : mine;
+            int r = 0;                                        // length of the run
+            for (int at = s;; at += 64) {
+                const int idx = at + lane;
+                const unsigned long long m = __ballot(idx < total && L.s.sg[idx] == bs);
+                const int rr = (~m) ? __builtin_ctzll(~m) : 64;
+                r += rr;
+                if (rr < 64) break;
+            }
+            float acc = __uint_as_float(L.s.px[s]);
+            const float *cs = L.s.pc + s;
+            uint32_t *ws = L.s.px + s;
+            // every lane stores the same eight words (one LDS write each, no lane selection: the instruction count of the
+            // chain is what a wave pays for when it shares its SIMD with the waves of other workgroups)
+            auto put8 = [&](int at, float w0, float w1, float w2, float w3, float w4, float w5, float w6, float w7) {
+                ws[at] = __float_as_uint(w0); ws[at + 1] = __float_as_uint(w1); ws[at + 2] = __float_as_uint(w2);
+                ws[at + 3] = __float_as_uint(w3); ws[at + 4] = __float_as_uint(w4); ws[at + 5] = __float_as_uint(w5);
+                ws[at + 6] = __float_as_uint(w6); ws[at + 7] = __float_as_uint(w7);
+            };
+            int j = 0;
+            if (r >= 8) {
+                float n0 = cs[0], n1 = cs[1], n2 = cs[2], n3 = cs[3], n4 = cs[4], n5 = cs[5], n6 = cs[6], n7 = cs[7];
+                for (; j + 16 <= r; j += 8) {
+                    const float c0 = n0, c1 = n1, c2 = n2, c3 = n3, c4 = n4, c5 = n5, c6 = n6, c7 = n7;
+                    n0 = cs[j + 8]; n1 = cs[j + 9]; n2 = cs[j + 10]; n3 = cs[j + 11];
+                    n4 = cs[j + 12]; n5 = cs[j + 13]; n6 = cs[j + 14]; n7 = cs[j + 15];
+                    const float w0 = acc + c0, w1 = w0 + c1, w2 = w1 + c2, w3 = w2 + c3, w4 = w3 + c4, w5 = w4 + c5, w6 = w5 + c6, w7 = w6 + c7;
+                    acc = w7;
+                    put8(j, w0, w1, w2, w3, w4, w5, w6, w7);
                 }
-                if (act) {
-                    L.s.po[idx] = (mine >= thr && mine - c < thr) ? oCross : 0;
-                    L.s.pc[idx] = mine;
-                }
-                if (r < 64) break;
+                const float w0 = acc + n0, w1 = w0 + n1, w2 = w1 + n2, w3 = w2 + n3, w4 = w3 + n4, w5 = w4 + n5, w6 = w5 + n6, w7 = w6 + n7;
+                acc = w7;
+                put8(j, w0, w1, w2, w3, w4, w5, w6, w7);
+                j += 8;
+            }
+            for (; j < r; ++j) {
+                acc += cs[j];
+                ws[j] = __float_as_uint(acc);
             }
             if (lane == 0) fin[s] = make_int2(bucket * 4 + slot, __float_as_int(acc));
         }
     }
     __syncthreads();
+    CAFE_STAMP(g.prof, 5);
     for (int s = tid; s < total; s += kThreads) {
         const uint32_t tm = L.s.stm[s];
+        const float run = __uint_as_float(L.s.px[s]), c = L.s.pc[s];
         hkey[o0 + s] = ((unsigned long long)L.s.sg[s] << 39) | ((unsigned long long)tm << 16);
-        hrun[o0 + s] = L.s.pc[s];
-        outm[tm >> 1] = L.s.po[s];
+        hrun[o0 + s] = run;
+        outm[tm >> 1] = (run >= thr && run - c < thr) ? oCross : 0;         // sketch.cpp:218-220
     }
 }
 
@@ -664,8 +785,8 @@ struct MainArgs {
 // partition's region, so a partition that is not re-run in a later round keeps its staged result.
 // Round 1 (MOVES = false) replays the class C items only; a later round replays every item of the partition together
 // with the moves the last LRU round addressed to it, all in time order.
-template <int CAP, bool MOVES>
-__device__ inline void main_owner(OwnerLds<CAP> &L, int *heavy, int *n_heavy, float *fsum, const Geo &g, int p, int round,
+template <int CAP, bool MOVES, bool MV>
+__device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy, float *fsum, const Geo &g, int p, int round,
                                   const MainArgs &A, const Score &sc) {
     const int tid = threadIdx.x;
     const uint32_t o0 = A.off[2 * p], oM = A.off[2 * p + 1], o1 = A.off[2 * p + 2];
@@ -708,6 +829,7 @@ __device__ inline void main_owner(OwnerLds<CAP> &L, int *heavy, int *n_heavy, fl
     }
     if (tid == 0) { A.stage_tot[p] = (uint32_t)total; *n_heavy = 0; }
     if (total == 0) return;
+    CAFE_STAMP_VAL(g.prof, 7, 3ull | ((unsigned long long)total << 8));
     field_sums(g, sc, fsum);
     const int b0 = p * g.bpp1;
     const Rec *recs = A.rec1 + o0;
@@ -722,7 +844,7 @@ __device__ inline void main_owner(OwnerLds<CAP> &L, int *heavy, int *n_heavy, fl
             const Rec r = recs[j];
             L.t.grp[j] = r.bl & ~kMissBit;
             if (MOVES) L.t.tpos[j] = 2u * r.pos;
-        } else {
+        } else if (MOVES) {
             const MoveEv m = A.ev[evbase + (j - np)];
             L.t.grp[j] = (uint32_t)(fast_hash(m.x, g.fm1) - b0);
             L.t.tpos[j] = m.time;
@@ -752,7 +874,9 @@ __device__ inline void main_owner(OwnerLds<CAP> &L, int *heavy, int *n_heavy, fl
         }
         __syncthreads();
     }
-    lsd_sort<CAP>(L.t, total, g.bits1, MOVES);
+    CAFE_STAMP(g.prof, 1);
+    lsd_sort<CAP, MV>(L.t, total, g.bits1, MOVES);
+    CAFE_STAMP(g.prof, 2);
     constexpr int IPT = CAP / kThreads;
     uint16_t myr[IPT];
 #pragma unroll
@@ -769,8 +893,8 @@ __device__ inline void main_owner(OwnerLds<CAP> &L, int *heavy, int *n_heavy, fl
                 L.s.sg[s] = r.bl & ~kMissBit; L.s.stm[s] = 2u * r.pos; L.s.px[s] = r.x; L.s.pc[s] = ss.at(r.pos);
                 // what the last round (or the plan) said about the item: 1 = missed
                 L.s.po[s] = MOVES ? A.miss[r.pos] : (uint8_t)((r.bl & kMissBit) ? 1 : 0);
-                L.s.pm[s] = 0;
-            } else {
+                if (MOVES) L.s.pm[s] = 0;
+            } else if (MOVES) {
                 const int e = j - np;
                 const MoveEv m = A.ev[evbase + e];
                 L.s.sg[s] = (uint32_t)(fast_hash(m.x, g.fm1) - b0); L.s.stm[s] = m.time; L.s.px[s] = m.x; L.s.pc[s] = m.cnt;
@@ -781,6 +905,7 @@ __device__ inline void main_owner(OwnerLds<CAP> &L, int *heavy, int *n_heavy, fl
     }
     __syncthreads();
 
+    CAFE_STAMP(g.prof, 3);
     const float thr = A.st->thr;
     const uint32_t gflip = (uint32_t)A.st->flip;
     MainBucket *stage = A.stage_m + o0 + (size_t)p * kCapEv;
@@ -834,6 +959,7 @@ __device__ inline void main_owner(OwnerLds<CAP> &L, int *heavy, int *n_heavy, fl
         store_main(&stage[s], b, b0 + (int)bl);
     }
     __syncthreads();
+    CAFE_STAMP(g.prof, 4);
     // Phase B: heavy buckets, one per wave at a time.  All 64 lanes carry the same bucket copy.  A run of
     // consecutive probes of one id that sits in the bucket only needs the ordered float sum of the scores on
     // the serial path (one readlane + add per item); threshold crossing and the pop are then evaluated for 64
@@ -954,6 +1080,7 @@ __device__ inline void main_owner(OwnerLds<CAP> &L, int *heavy, int *n_heavy, fl
         }
     }
     __syncthreads();
+    CAFE_STAMP(g.prof, 5);
     // parallel write-back of the per-item outcomes; entries that are not a bucket's first item are marked unused
     for (int s = tid; s < total; s += kThreads) {
         const uint32_t time = L.s.stm[s];
@@ -1003,8 +1130,8 @@ struct LruArgs {
 
 // Replays the items of LRU partition q that missed the main table (round 1: the presumed misses of the plan), in
 // batch order per bucket, and hands every move out of the table to the main partition of its target bucket.
-template <int CAP>
-__device__ inline void lru_owner(OwnerLds<CAP> &L, int *n_ev, int *s_total, float *fsum, const Geo &g, int q, int round,
+template <int CAP, bool MV>
+__device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *n_ev, int *s_total, float *fsum, const Geo &g, int q, int round,
                                  const LruArgs &A, const Score &sc) {
     const int tid = threadIdx.x;
     const int par = round & 1, nxt = par ^ 1;
@@ -1028,6 +1155,7 @@ __device__ inline void lru_owner(OwnerLds<CAP> &L, int *n_ev, int *s_total, floa
     }
     if (tid == 0) *n_ev = 0;
     if (cnt == 0) { if (tid == 0) { A.stage_tot[g.P1 + q] = 0; A.mycnt[q] = 0; } return; }
+    CAFE_STAMP_VAL(g.prof, 7, 2ull | ((unsigned long long)cnt << 8));
     field_sums(g, sc, fsum);
     const int b0 = q * g.bpp2;
     const Rec *recs = A.rec2 + o0;
@@ -1049,7 +1177,9 @@ __device__ inline void lru_owner(OwnerLds<CAP> &L, int *n_ev, int *s_total, floa
     const int nmiss = *s_total;
     if (tid == 0) { A.stage_tot[g.P1 + q] = (uint32_t)nmiss; if (nmiss == 0) A.mycnt[q] = 0; }
     if (nmiss == 0) return;
-    lsd_sort<CAP>(L.t, cnt, g.bits2 + 1, false);
+    CAFE_STAMP(g.prof, 1);
+    lsd_sort<CAP, MV>(L.t, cnt, g.bits2 + 1, false);
+    CAFE_STAMP(g.prof, 2);
     constexpr int IPT = CAP / kThreads;
     uint16_t myr[IPT];
 #pragma unroll
@@ -1067,6 +1197,7 @@ __device__ inline void lru_owner(OwnerLds<CAP> &L, int *n_ev, int *s_total, floa
     }
     __syncthreads();
 
+    CAFE_STAMP(g.prof, 3);
     const float thr = A.st->thr;
     const uint32_t gflip = (uint32_t)A.st->flip;
     LruBucket *stage = A.stage_l + o0;
@@ -1108,6 +1239,7 @@ __device__ inline void lru_owner(OwnerLds<CAP> &L, int *n_ev, int *s_total, floa
         store_lru(&stage[s], b, b0 + (int)bl);
     }
     __syncthreads();
+    CAFE_STAMP(g.prof, 4);
     if (tid == 0) {
         A.mycnt[q] = (uint32_t)min(*n_ev, kCapEvL);
         if (round == 1 && *n_ev) atomicAdd(&A.ctl->nmoves, (uint32_t)*n_ev);
@@ -1132,28 +1264,30 @@ struct HotArgs {
 
 template <int CAP>
 __global__ void __launch_bounds__(kThreads) k_round1(Geo g, MainArgs MA, LruArgs LA, HotArgs HA, Score sc) {
-    __shared__ __attribute__((aligned(16))) OwnerLds<CAP> L;
+    __shared__ __attribute__((aligned(16))) OwnerLds<CAP, false> L;
     __shared__ int heavy[kMaxHeavy];
     __shared__ int n_heavy, s_total;
     __shared__ float fsum[kMaxSeg];
-    if (MA.ctl->overflow) return;
-    CAFE_STAMP(0);
+    // (no look at the control word here: owners only write staging buffers, and k_finish / k_commit refuse a batch whose
+    // control word reports a limit -- one memory round trip less in every owner)
+    CAFE_STAMP_VAL(0, 7, 0ull);
+    CAFE_STAMP(0, 0);
     int b = blockIdx.x;
     const int nhot = g.hot ? g.P1 : 0;
     if (b < nhot) {
-        hot_owner<CAP>(L, heavy, &n_heavy, fsum, g, b, MA.mt, MA.st, MA.ctl, MA.off, HA.rech, sc, HA.hkey, HA.hrun, HA.hfin, MA.outm);
-        CAFE_STAMP(1);
+        hot_owner<CAP, false>(L, heavy, &n_heavy, fsum, g, b, MA.mt, MA.st, MA.ctl, MA.off, HA.rech, sc, HA.hkey, HA.hrun, HA.hfin, MA.outm);
+        CAFE_STAMP(0, 6);
         return;
     }
     b -= nhot;
     if (b < g.P2) {
-        lru_owner<CAP>(L, &n_heavy, &s_total, fsum, g, b, 1, LA, sc);
-        CAFE_STAMP(2);
+        lru_owner<CAP, false>(L, &n_heavy, &s_total, fsum, g, b, 1, LA, sc);
+        CAFE_STAMP(0, 6);
         return;
     }
     b -= g.P2;
-    main_owner<CAP, false>(L, heavy, &n_heavy, fsum, g, b, 1, MA, sc);
-    CAFE_STAMP(3);
+    main_owner<CAP, false, false>(L, heavy, &n_heavy, fsum, g, b, 1, MA, sc);
+    CAFE_STAMP(0, 6);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1193,7 +1327,8 @@ __device__ inline bool grid_barrier(Ctl *ctl, uint32_t &gen) {
 
 template <int CAP>
 __global__ void __launch_bounds__(kThreads) k_fix(Geo g, MainArgs MA, LruArgs LA, Score sc) {
-    __shared__ __attribute__((aligned(16))) OwnerLds<CAP> L;
+    g.prof = 5;
+    __shared__ __attribute__((aligned(16))) OwnerLds<CAP, true> L;
     __shared__ int heavy[kMaxHeavy];
     __shared__ int n_heavy, s_total;
     __shared__ float fsum[kMaxSeg];
@@ -1212,7 +1347,7 @@ __global__ void __launch_bounds__(kThreads) k_fix(Geo g, MainArgs MA, LruArgs LA
             // partitions that have moves now, or ran with moves before (they may have to run without)
             const uint32_t need = tid == 0 ? (MA.evcnt[prev * g.P1 + p] | MA.prevcnt[p]) : 0u;
             if (!__syncthreads_or(need != 0)) continue;
-            main_owner<CAP, true>(L, heavy, &n_heavy, fsum, g, p, round, MA, sc);
+            main_owner<CAP, true, true>(L, heavy, &n_heavy, fsum, g, p, round, MA, sc);
             __syncthreads();
         }
         if (!grid_barrier(ctl, gen)) { if (tid == 0) ctl->overflow = 1; return; }
@@ -1225,7 +1360,7 @@ __global__ void __launch_bounds__(kThreads) k_fix(Geo g, MainArgs MA, LruArgs LA
         const int par = round & 1, nxt = par ^ 1;
         for (int p = blockIdx.x * kThreads + tid; p < g.P1; p += gridDim.x * kThreads) LA.evcnt[nxt * g.P1 + p] = 0;
         for (int q = blockIdx.x; q < g.P2; q += gridDim.x) {
-            lru_owner<CAP>(L, &n_heavy, &s_total, fsum, g, q, round, LA, sc);
+            lru_owner<CAP, true>(L, &n_heavy, &s_total, fsum, g, q, round, LA, sc);
             __syncthreads();
         }
         if (!grid_barrier(ctl, gen)) { if (tid == 0) ctl->overflow = 1; return; }
@@ -1247,10 +1382,11 @@ __global__ void __launch_bounds__(kScanBlock) k_finish(
     float *__restrict__ scores_out) {
     __shared__ uint32_t wsum[3][kScanBlock / 64];
     __shared__ uint32_t s_cross;
-    __shared__ uint32_t s_base[3];
+    __shared__ uint32_t s_base[4];
     __shared__ float fsum[kMaxSeg];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = blockIdx.x * kScanBlock + tid;
+    CAFE_STAMP(1, 0);
     if (scores_out) {
         // the scores as every owner formed them, for the caller (sk_embedding_bag.py:189)
         field_sums(g, sc, fsum);
@@ -1258,6 +1394,7 @@ __global__ void __launch_bounds__(kScanBlock) k_finish(
         const ScoreSrc ss = score_src(g, sc, fsum);
         if (i < g.n) scores_out[i] = ss.at((uint32_t)i);
     }
+    CAFE_STAMP(1, 1);
     const bool live = !ctl->overflow && ctl->final_round != 0;
     if (!live) return;             // uniform; k_commit decides what happens to the batch
     if (tid == 0) s_cross = 0;
@@ -1283,6 +1420,7 @@ __global__ void __launch_bounds__(kScanBlock) k_finish(
         if (cross && g.seg > 0) atomicAdd(&ctl->segcross[i / g.seg], 1u);      // a few hundred per call
         if (got) gotlist[atomicAdd(&ctl->ngot, 1u)] = (uint32_t)i;
     }
+    CAFE_STAMP(1, 2);
     const unsigned long long below = lanes_below();
     const unsigned long long m0 = __ballot(pop), m1 = __ballot(push), m2 = __ballot(clk), mx = __ballot(cross);
     if (lane == 0) { wsum[0][w] = __popcll(m0); wsum[1][w] = __popcll(m1); wsum[2][w] = __popcll(m2); }
@@ -1294,35 +1432,47 @@ __global__ void __launch_bounds__(kScanBlock) k_finish(
         t0 += wsum[0][k]; t1 += wsum[1][k]; t2 += wsum[2][k];
     }
     __syncthreads();
-    if (w == 0) {
-        // publish this workgroup's totals, then sum the words in front of it
-        if (lane == 0) {
-            __hip_atomic_store(&agg[2 * blockIdx.x], (1ull << 63) | ((unsigned long long)t0 << 24) | t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&agg[2 * blockIdx.x + 1], (1ull << 63) | (unsigned long long)t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            atomicAdd(&ctl->totals[0], t0); atomicAdd(&ctl->totals[1], t1); atomicAdd(&ctl->totals[2], t2);
-            atomicAdd(&ctl->totals[3], s_cross);
-        }
-        unsigned long long a0 = 0, a1 = 0, a2 = 0;
-        for (int base = (int)blockIdx.x - 1; base >= 0; base -= 64) {
-            const int bq = base - lane;
-            if (bq >= 0) {
-                unsigned long long v0, v1;
-                long spins = 0;
-                do { v0 = __hip_atomic_load(&agg[2 * bq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v0 >> 63) && ++spins < (1L << 26));
-                do { v1 = __hip_atomic_load(&agg[2 * bq + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v1 >> 63) && ++spins < (1L << 26));
-                if (!(v0 >> 63) || !(v1 >> 63)) ctl->overflow = 1;         // never seen; k_commit then refuses the batch
-                a0 += (v0 >> 24) & 0xffffffull; a1 += v0 & 0xffffffull; a2 += v1 & 0xffffffull;
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
-        if (lane == 0) { s_base[0] = (uint32_t)a0; s_base[1] = (uint32_t)a1; s_base[2] = (uint32_t)a2; }
+    // publish this workgroup's totals, then sum the words in front of it: a lane per workgroup in front, all waves at once
+    if (tid == 0) {
+        __hip_atomic_store(&agg[2 * blockIdx.x], (1ull << 63) | ((unsigned long long)t0 << 24) | t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&agg[2 * blockIdx.x + 1], (1ull << 63) | ((unsigned long long)s_cross << 24) | t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_base[0] = s_base[1] = s_base[2] = s_base[3] = 0;
     }
     __syncthreads();
+    {
+        unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int bq = (int)blockIdx.x - 1 - tid; bq >= 0; bq -= kScanBlock) {
+            unsigned long long v0 = __hip_atomic_load(&agg[2 * bq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long v1 = __hip_atomic_load(&agg[2 * bq + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long spins = 0;
+            while (!(v0 >> 63) && ++spins < (1L << 24)) v0 = __hip_atomic_load(&agg[2 * bq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (!(v1 >> 63) && ++spins < (1L << 24)) v1 = __hip_atomic_load(&agg[2 * bq + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(v0 >> 63) || !(v1 >> 63)) ctl->overflow = 1;         // never seen; k_commit then refuses the batch
+            a0 += (v0 >> 24) & 0xffffffull; a1 += v0 & 0xffffffull; a2 += v1 & 0xffffffull; a3 += (v1 >> 24) & 0xffffffull;
+        }
+        if (__ballot(a0 | a1 | a2 | a3)) {
+            for (int o = 32; o > 0; o >>= 1) {
+                a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); a3 += __shfl_xor(a3, o, 64);
+            }
+            if (lane == 0) {
+                atomicAdd(&s_base[0], (uint32_t)a0); atomicAdd(&s_base[1], (uint32_t)a1); atomicAdd(&s_base[2], (uint32_t)a2);
+                atomicAdd(&s_base[3], (uint32_t)a3);
+            }
+        }
+    }
+    __syncthreads();
+    CAFE_STAMP(1, 3);
     if (i < g.n) {
         poprank[i] = s_base[0] + b0 + (uint32_t)__popcll(m0 & below);
         pushrank[i] = s_base[1] + b1 + (uint32_t)__popcll(m1 & below);
         clkrank[i] = s_base[2] + b2 + (uint32_t)__popcll(m2 & below);
     }
+    // the last workgroup's sums are the batch totals (no contended atomics: 200 workgroups adding to one line cost ~10 us)
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        ctl->totals[0] = s_base[0] + t0; ctl->totals[1] = s_base[1] + t1; ctl->totals[2] = s_base[2] + t2;
+        ctl->totals[3] = s_base[3] + s_cross;
+    }
+    CAFE_STAMP(1, 4);
 }
 
 __device__ inline int32_t resolve_dic(int32_t d, const uint32_t *fifo, uint32_t cap, uint32_t head, const uint32_t *poprank,
@@ -1369,18 +1519,22 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
     const int tid = threadIdx.x;
     DevState *st = A.st;
     const Ctl *ctl = A.ctl;
-    // every workgroup takes the same decision from the same words (none of them changes before the last one is done)
+    CAFE_STAMP(2, 0);
+    // every workgroup takes the same decision from the same words (none of them changes before the last one is done);
+    // all of them are requested before the first is looked at
     if (tid < 64) {
-        const uint32_t len0 = st->fifo_len;
-        int reason = 0;
-        if (ctl->overflow) reason = 1;
-        else if (ctl->final_round == 0) reason = 2;
-        else if (len0 > 0 ? ctl->totals[0] > len0 : ctl->totals[1] != 0) reason = 3;       // never ran dry / never refilled
-        // sketch.cpp:291 at the inner boundaries, with the crossings counted per segment
+        const uint32_t len0 = st->fifo_len, w_over = ctl->overflow, w_final = ctl->final_round, w_pop = ctl->totals[0],
+                       w_push = ctl->totals[1];
+        const int32_t real_n = st->real_n;
         const int nseg = g.seg > 0 ? (g.n + g.seg - 1) / g.seg : 0;
         long run = tid < nseg - 1 ? (long)ctl->segcross[tid] : 0;
+        int reason = 0;
+        if (w_over) reason = 1;
+        else if (w_final == 0) reason = 2;
+        else if (len0 > 0 ? w_pop > len0 : w_push != 0) reason = 3;       // never ran dry / never refilled
+        // sketch.cpp:291 at the inner boundaries, with the crossings counted per segment
         for (int o = 1; o < 64; o <<= 1) { const long v = __shfl_up(run, o, 64); if (tid >= o) run += v; }
-        const bool fires = tid < nseg - 1 && (double)(run + st->real_n) > A.reset_at;
+        const bool fires = tid < nseg - 1 && (double)(run + real_n) > A.reset_at;
         if (!reason && __ballot(fires)) reason = 4;
         if (tid == 0) {
             s_reason = reason;
@@ -1389,6 +1543,7 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
     }
     __syncthreads();
     const int verdict = s_verdict;
+    CAFE_STAMP(2, 1);
     const uint32_t head = st->fifo_head, len0 = st->fifo_len;
     const int32_t clk0 = st->clk;
     if (verdict == 0) {
@@ -1460,12 +1615,25 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
             }
         }
     }
+    CAFE_STAMP(2, 2);
     // the look-back words of k_finish start at zero in the next call
     for (int i = blockIdx.x * blockDim.x + tid; i < 2 * A.nagg; i += gridDim.x * blockDim.x) A.agg[i] = 0;
     // ---- close the call: the workgroup that finishes last (every workgroup has read the scalars by then) ----
     __syncthreads();
-    if (tid == 0) s_last = __hip_atomic_fetch_add(&A.ctl->ticket_commit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    if (tid == 0) {
+        // two levels (a thousand workgroups queueing for one word cost ~12 ns each): 32 sub-counters, whoever completes
+        // one goes on to the top counter
+        const uint32_t sub = blockIdx.x & 31u;
+        const uint32_t quota = (gridDim.x - sub + 31u) / 32u;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&A.ctl->ticket_sub[sub * 16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == quota - 1) {
+            const uint32_t subs = min(32u, gridDim.x);
+            last = __hip_atomic_fetch_add(&A.ctl->ticket_commit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == subs - 1;
+        }
+        s_last = last;
+    }
     __syncthreads();
+    CAFE_STAMP(2, 3);
     if (!s_last) return;
     const int reason = s_reason;
     Mirror *mr = A.mirror;
@@ -1520,6 +1688,7 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
         __threadfence_system();
         mr->seq = A.seq;
     }
+    CAFE_STAMP(2, 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1593,9 +1762,49 @@ static int pick_cap(cafe_sketch *s, int n) {
     if (s->last_seen_batch != n || m->seq == 0) { s->last_seen_batch = n; return 2048; }
     const long big = std::max(m->st.maxpart, m->st.pad[3]);
     if (m->st.fallback) return 8192;
-    if (big * 5 / 4 + 64 <= 1024) return 1024;
-    if (big * 5 / 4 + 64 <= 2048) return 2048;
+    if (big + big / 8 + 32 <= 1024) return 1024;
+    if (big + big / 8 + 32 <= 2048) return 2048;
     return 8192;
+}
+
+// The plan of an insert of n ids: classification, partition offsets, item records; per-call scalars and a zeroed
+// control block.  Reads the ids and the pre-batch tables only.
+static int launch_plan(cafe_sketch *s, Geo &g, const IdSrc &ids, hipStream_t pre) {
+    ParWorkspace &w = *s->par;
+    const int n = g.n;
+    Ctl *ctl = w.ctl.as<Ctl>();
+    uint32_t *evcnt = w.ctl.as<uint32_t>() + kCtlWords;
+    uint32_t *off = w.off.as<uint32_t>();
+    uint32_t *planA = w.plan.as<uint32_t>(), *planB = planA + n;
+    Rec *rec1 = w.items.as<Rec>(), *rec2 = rec1 + n, *rech = rec2 + n;
+    const size_t plan_lds = 2 * (size_t)kPlanWaves * g.nbins + 16;
+    static size_t plan_lds_set = 48 * 1024;
+    if (plan_lds > plan_lds_set) {
+        CAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds));
+        plan_lds_set = plan_lds;
+    }
+    hipLaunchKernelGGL(k_assign, dim3(g.nchunks), dim3(kPlanThreads), plan_lds, pre, g, s->d_main, ids, w.cm.as<uint16_t>(), planA, planB);
+    hipLaunchKernelGGL(k_offsets, dim3((g.nbins + kOffBins - 1) / kOffBins), dim3(kThreads), 0, pre, g, w.cm.as<uint16_t>(),
+                       w.colpref.as<uint32_t>(), w.tot.as<uint32_t>(), off, ctl, evcnt, s->d_state);
+    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, pre, g, ids, planA, planB, w.colpref.as<uint32_t>(), off, rec1, rec2,
+                       rech, w.miss.as<uint8_t>());
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// cafe_forward_dev: the plan of the insert that will follow this forward, on the handle's second stream beside the
+// gather kernel.  It stands if the next insert is over the same ids with no call, flip or reset in between.
+int par_plan_ahead(cafe_sketch *s, const int64_t *d_local_ids, const int64_t *d_id_offset, int batch, int n, hipStream_t side) {
+    Geo g;
+    if (ensure_ws(s, n, g)) return 1;
+    g.flip_now = 0;
+    IdSrc ids;
+    ids.gids = nullptr; ids.local_ids = d_local_ids; ids.id_offset = d_id_offset; ids.batch = batch;
+    if (launch_plan(s, g, ids, side)) return 1;
+    CAFE_HIP_CHECK(hipEventRecord(s->ev_plan, side));
+    s->plan_valid = 1; s->plan_seq = s->call_seq; s->plan_n = n; s->plan_ids = d_local_ids; s->plan_flip = s->flip;
+    s->plan_hot = s->opt_hot_bypass; s->plan_target = s->opt_target_items;
+    return 0;
 }
 
 int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const float *d_psum, int nparts, int n,
@@ -1611,31 +1820,28 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     const unsigned long long tag = w.call_seq;
     Ctl *ctl = w.ctl.as<Ctl>();
     uint32_t *evcnt = w.ctl.as<uint32_t>() + kCtlWords;
-    uint32_t *gotcount = w.ctl.as<uint32_t>() + kCtlWords + 2 * (size_t)kMaxParts + 4;
-    (void)gotcount;
     uint32_t *off = w.off.as<uint32_t>();
-    uint32_t *planA = w.plan.as<uint32_t>(), *planB = planA + n;
     Rec *rec1 = w.items.as<Rec>(), *rec2 = rec1 + n, *rech = rec2 + n;
-    const int gb = (n + 255) / 256;
     Score sc;
     sc.vals = d_vals; sc.psum = d_psum;
 
-    // ---- plan ----
-    const size_t plan_lds = 2 * (size_t)kPlanWaves * g.nbins + 16;
-    static size_t plan_lds_set = 48 * 1024;
-    if (plan_lds > plan_lds_set) {
-        CAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds));
-        plan_lds_set = plan_lds;
-    }
-    hipLaunchKernelGGL(k_assign, dim3(g.nchunks), dim3(kPlanThreads), plan_lds, pre, g, s->d_main, d_ids,
-                       w.cm.as<uint16_t>(), planA, planB);
-    hipLaunchKernelGGL(k_offsets, dim3((g.nbins + kThreads - 1) / kThreads), dim3(kThreads), 0, pre, g, w.cm.as<uint16_t>(),
-                       w.colpref.as<uint32_t>(), w.tot.as<uint32_t>(), off, ctl, evcnt, s->d_state);
-    hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(256), 0, pre, g, d_ids, planA, planB, w.colpref.as<uint32_t>(), off, rec1, rec2,
-                       rech, w.miss.as<uint8_t>());
-    if (pre != st) {         // the scores come in here
-        CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, pre));
-        CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));
+    // ---- plan: the one made beside the forward, if it is still the plan of this call ----
+    const bool ahead = s->plan_valid && s->plan_seq + 1 == s->call_seq && s->plan_n == n && s->plan_ids == s->plan_expect && !flip_now &&
+                       s->plan_flip == s->flip && s->plan_hot == s->opt_hot_bypass && s->plan_target == s->opt_target_items &&
+                       !s->plan_stale;
+    s->plan_valid = 0;
+    s->plan_stale = 0;
+    if (ahead) {
+        CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_plan, 0));
+        s->counters_plan_ahead++;
+    } else {
+        IdSrc ids;
+        ids.gids = d_ids; ids.local_ids = nullptr; ids.id_offset = nullptr; ids.batch = 1;
+        if (launch_plan(s, g, ids, pre)) return 1;
+        if (pre != st) {         // the scores come in here
+            CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, pre));
+            CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));
+        }
     }
     // ---- rounds ----
     MainArgs MA;
@@ -1679,7 +1885,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     CA.mirror = reinterpret_cast<Mirror *>(s->d_pinned); CA.seq = s->call_seq;
     CA.reset_at = s->adjust ? s->lim * 1.2 : 1e300;
     CA.gotcount = w.ctl.as<uint32_t>() + kCtlWords + 2 * (size_t)kMaxParts + 4;
-    const int cb = std::min(g.P1 + g.P2, 1024);
+    const int cb = g.P1 + g.P2;
     hipLaunchKernelGGL(k_commit, dim3(cb), dim3(256), 0, st, g, CA, sc);
     if (s->ev_chain[1]) (void)hipEventRecord(s->ev_chain[1], st);
     CAFE_HIP_CHECK(hipGetLastError());

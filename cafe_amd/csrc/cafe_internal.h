@@ -66,6 +66,13 @@ struct cafe_sketch {
     hipStream_t side_stream = nullptr;
     int opt_overlap = 3;
     hipEvent_t ev_head_fork = nullptr, ev_head_join = nullptr;
+    hipEvent_t ev_plan = nullptr;       // plan made beside the forward (cafe_forward_dev) is complete
+    // the plan cafe_forward_dev made for the insert that follows it: valid for call plan_seq + 1 over the ids at plan_ids
+    int plan_valid = 0, plan_n = 0, plan_flip = 0, plan_hot = 0, plan_target = 0, plan_stale = 0;
+    uint32_t plan_seq = 0;
+    const void *plan_ids = nullptr, *plan_expect = nullptr;   // plan_expect: the ids of the insert being issued
+    int opt_plan_ahead = 1, unused_plans = 0;
+    long long counters_plan_ahead = 0;
     hipEvent_t ev_done = nullptr;       // recorded behind the closing kernel of every insert
     int ev_done_valid = 0;
     long long last_seen_batch = -1;
@@ -112,6 +119,7 @@ constexpr int kParMaxIds = 1 << 21;     // largest batch of the parallel insert 
 int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const float *d_psum, int nparts, int n,
                int32_t *d_ins, float *d_scores_out, int flip_now, hipStream_t st, hipStream_t pre);
 int par_prepare(cafe_sketch *s, int n);          // sizes the workspaces (may allocate: before any kernel of the call)
+int par_plan_ahead(cafe_sketch *s, const int64_t *d_local_ids, const int64_t *d_id_offset, int batch, int n, hipStream_t side);
 void par_free(cafe_sketch *s);
 // what the last parallel insert leaves for the migration: number of newly hot lookups (0xffffffff: scan ins[]) and
 // their batch positions

@@ -351,6 +351,7 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_fork, hipEventDisableTiming));
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_join, hipEventDisableTiming));
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_plan, hipEventDisableTiming));
     if (s->ws_misc.reserve(4096)) return 1;
     CAFE_HIP_CHECK(hipMemset(s->d_main, 0, sizeof(MainBucket) * (size_t)s->n1));
     CAFE_HIP_CHECK(hipMemset(s->d_lru, 0, sizeof(LruBucket) * (size_t)s->n2));
@@ -372,6 +373,7 @@ extern "C" int cafe_sketch_destroy(cafe_sketch_t *s) {
     if (s->ev_head_fork) (void)hipEventDestroy(s->ev_head_fork);
     if (s->ev_head_join) (void)hipEventDestroy(s->ev_head_join);
     if (s->ev_done) (void)hipEventDestroy(s->ev_done);
+    if (s->ev_plan) (void)hipEventDestroy(s->ev_plan);
     s->ws_reset_keys.release(); s->ws_reset_keys2.release(); s->ws_reset_tmp.release();
     s->ws_reset_flags.release(); s->ws_misc.release();
     delete s;
@@ -384,6 +386,7 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
     else if (!strcmp(name, "target_items")) s->opt_target_items = value < 16 ? 16 : value;
     else if (!strcmp(name, "hot_bypass")) s->opt_hot_bypass = value ? 1 : 0;
     else if (!strcmp(name, "exact_reset")) (void)value;          // kept for callers of older builds: the decision is always exact
+    else if (!strcmp(name, "plan_ahead")) s->opt_plan_ahead = value ? 1 : 0;
     else if (!strcmp(name, "owner_cap")) s->force_cap = value == 1024 || value == 2048 || value == 8192 ? value : 0;
     else if (!strcmp(name, "overlap")) s->opt_overlap = value;
     else if (!strcmp(name, "fuse_fields")) s->opt_fuse_fields = value ? 1 : 0;
@@ -499,6 +502,7 @@ extern "C" int cafe_sketch_import(cafe_sketch_t *s, const int32_t *mval, const f
     CAFE_HIP_CHECK(hipMemcpy(s->d_fifo, hf.data(), 4 * hf.size(), hipMemcpyHostToDevice));
     CAFE_HIP_CHECK(hipMemcpy(s->d_state, &h, sizeof(h), hipMemcpyHostToDevice));
     s->flip = ints6[3]; s->batch_num = ints6[4]; s->decay = decay;
+    s->plan_valid = 0;
     s->base_real_n = h.real_n;
     s->base_seq = s->call_seq;
     s->host_thr = thr;
@@ -741,6 +745,7 @@ int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_val
             // the reference flips first (sketch.cpp:284-289), then resets (:291): the scalars go in ahead of the reset
             hipLaunchKernelGGL(k_prologue, dim3(1), dim3(64), 0, pre, s->d_state, flip_now, s->flip);
             flip_now = 0;
+            s->plan_stale = 1;                           // the tables change under a plan made beside the forward
             if (run_reset(s, pre)) return 1;
             s->base_real_n = s->lim;                     // sketch.cpp:113
             s->base_seq = s->call_seq;

@@ -1,4 +1,4 @@
-"""Diagnostic (not collected): per-owner phase times of the insert rounds on cfg3.
+"""Diagnostic (not collected): per-workgroup phase times inside the insert kernels on cfg3.
 Needs the stamp build: make -C cafe_amd/csrc clean && make -C cafe_amd/csrc EXTRA=-DCAFE_PROF"""
 import ctypes, sys
 import numpy as np
@@ -6,53 +6,53 @@ sys.path.insert(0, "/root/repo")
 import torch
 from cafe_amd.config import workload
 from cafe_amd.collection import CafeEmbeddingCollection
-wl = workload("cfg3")
+wl = workload(sys.argv[1] if len(sys.argv) > 1 else "cfg3")
 F, B, D = wl.num_fields, wl.batch, wl.dim
 eng = CafeEmbeddingCollection(wl.counts, D, wl.hotn, wl.hash_sizes, wl.offsets, threshold=wl.threshold, alpha=wl.alpha, seed=1)
-ids = [torch.from_numpy(x).cuda() for x in wl.make_ids(123, steps=8)]
+ids = [torch.from_numpy(x).cuda() for x in wl.make_ids(123, steps=16)]
 grad = torch.randn(F, B, D, device="cuda")
-for i in range(60):
-    eng.forward(ids[i % 8]); eng.backward_update(grad, 0.1, per_field_calls=True)
+for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 600):
+    eng.forward(ids[i % 16]); eng.backward_update(grad, 0.1, per_field_calls=True)
 torch.cuda.synchronize()
 L = eng.L
-buf = np.zeros(2 * 8192 * 8, np.uint64)
+buf = np.zeros(8 * 4096 * 8, np.uint64)
 L.cafe_debug_read.argtypes = [ctypes.c_void_p]
 L.cafe_debug_read(buf.ctypes.data)
-for t, (name, phases) in enumerate([("main", ["load+sort", "phaseA", "phaseB", "writeback"]), ("lru", ["load+sort", "replay", "writeback"])]):
-    b = buf.reshape(2, 8192, 8)[t].astype(np.int64)
+buf = buf.reshape(8, 4096, 8).astype(np.int64)
+
+
+def show(name, b, labels):
     b = b[b[:, 0] > 0]
     if not len(b):
-        continue
+        print(f"== {name}: no stamps"); return
     t0 = b[:, 0].min()
-    nh = b[:, 7] >> 32
-    tot = b[:, 7] & 0xffffffff
-    print("n_heavy: mean", nh.mean(), "max", nh.max())
-    n = len(phases)
-    print(f"== {name}: blocks {len(b)} items mean {tot.mean():.0f} max {tot.max()}")
-    for k in range(n):
-        d = (b[:, k + 1] - b[:, k]) / 100.0
-        print(f"{phases[k]:10s} mean {d.mean():7.2f} us  p50 {np.median(d):7.2f}  p99 {np.percentile(d, 99):7.2f}  max {d.max():7.2f}")
-    if t == 0:
-        d = (b[:, 5] - b[:, 1]) / 100.0
-        print(f"A: start->bucket loaded (wave 0) p50 {np.median(d):.2f} mean {d.mean():.2f}")
-        d = (b[:, 6] - b[:, 5]) / 100.0
-        print(f"A: replay of first bucket (wave 0) p50 {np.median(d):.2f} mean {d.mean():.2f}")
-        d = (b[:, 2] - b[:, 6]) / 100.0
-        print(f"A: first bucket done -> barrier passed p50 {np.median(d):.2f} mean {d.mean():.2f}")
-    if t == 1:
-        for nm, v in [("miss-loaded -> before barrier1", b[:, 4] >> 32), ("barrier1", b[:, 4] & 0xffffffff), ("rank_of", b[:, 5] >> 32), ("barrier2 + writes + barrier3", b[:, 5] & 0xffffffff)]:
-            print(f"L cycles: {nm}: p50 {np.median(v):.0f} mean {v.mean():.0f} p99 {np.percentile(v, 99):.0f}")
-    if False:
-        for nm, x, y in [("entry->flags read", 4, 5), ("flags->first barrier (off, ldirty)", 5, 0), ("barrier->rec loaded", 0, 6), ("rec loaded->sorted (miss gather, rank)", 6, 1)]:
-            dd = (b[:, y] - b[:, x]) / 100.0
-            print(f"L: {nm}: p50 {np.median(dd):.2f} mean {dd.mean():.2f} p99 {np.percentile(dd, 99):.2f}")
-    d = (b[:, n] - b[:, 0]) / 100.0
-    print(f"block total mean {d.mean():.2f} p50 {np.median(d):.2f} max {d.max():.2f}; first start->last start {(b[:, 0].max() - t0) / 100.0:.2f}; last end {(b[:, n].max() - t0) / 100.0:.2f}")
-    for o in np.argsort(-d)[:5]:
-        print("  slow: items", tot[o], "heavy", nh[o], "total", d[o], "phases", [float((b[o, k + 1] - b[o, k]) / 100.0) for k in range(n)], "start", (b[o, 0] - t0) / 100.0,
-              ("A parts", float((b[o, 5] - b[o, 1]) / 100.0), float((b[o, 6] - b[o, 5]) / 100.0), float((b[o, 2] - b[o, 6]) / 100.0)) if t == 0 else "")
-    st = (b[:, 0] - t0) / 100.0
-    for lo, hi in [(0, 1), (1, 10), (10, 20), (20, 30), (30, 40), (40, 60)]:
-        sel = (st >= lo) & (st < hi)
-        if sel.sum():
-            print(f"  start in [{lo},{hi}) us: {sel.sum()} blocks, items mean {tot[sel].mean():.0f}, block total p50 {np.median(d[sel]):.2f} mean {d[sel].mean():.2f}")
+    print(f"== {name}: {len(b)} workgroups; first start -> last start {(b[:, 0].max() - t0) / 100:.2f} us")
+    prev = 0
+    for k, lab in labels:
+        ok = b[:, k] > 0
+        if not ok.any():
+            continue
+        d = (b[ok, k] - b[ok, prev]) / 100.0
+        e = (b[ok, k] - t0) / 100.0
+        print(f"   {lab:28s} n={ok.sum():5d} phase mean {d.mean():6.2f} p50 {np.median(d):6.2f} p99 {np.percentile(d, 99):6.2f} max {d.max():6.2f} | ends at p50 {np.median(e):6.2f} max {e.max():6.2f}")
+        prev = k
+
+
+r1 = buf[0]
+role = r1[:, 7] & 0xff
+tot = r1[:, 7] >> 8
+for rid, rn in [(1, "hot"), (2, "lru"), (3, "main C")]:
+    sel = (role == rid) & (r1[:, 0] > 0)
+    if sel.any():
+        print(f"-- round1 {rn}: items mean {tot[sel].mean():.0f} max {tot[sel].max()}")
+        show(f"round1 {rn}", r1[sel], [(1, "sums+load"), (2, "sort"), (3, "scatter to sorted"), (4, "lane replay"), (5, "heavy/wave replay"), (6, "write-out")])
+        d = (r1[sel, 6] - r1[sel, 0]) / 100.0
+        o = np.argsort(-d)[:4]
+        print("   slowest:", [(int(tot[sel][i]), float(d[i])) for i in o])
+        for i in o[:3]:
+            row = r1[sel][i]
+            print("      items", int(tot[sel][i]), "phase ends (us from block start):", [round(float(row[k] - row[0]) / 100.0, 2) if row[k] > 0 else None for k in range(1, 7)])
+show("finish", buf[1], [(1, "scores out"), (2, "flags"), (3, "look-back"), (4, "ranks")])
+show("commit", buf[2], [(1, "verdict"), (2, "partitions"), (3, "ticket"), (4, "close (last)")])
+show("offsets", buf[3], [(1, "column sums"), (2, "prefix+ticket"), (3, "bin scans (last)"), (4, "zero+scalars (last)")])
+print(eng.sketch.counters())

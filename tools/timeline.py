@@ -5,16 +5,28 @@
 A step starts at a k_forward launch.  Prints every kernel of the chosen step with its start/end relative to the
 step's start, the queue it ran on and the gap to the previous kernel on that queue, then the median step length
 over the last 100 steps and the per-kernel medians."""
-import csv, glob, re, sys, statistics as st
+import csv, glob, os, re, sys, statistics as st
 from collections import defaultdict
 
 p = sys.argv[1]
-f = p if p.endswith(".csv") else glob.glob(p + "/**/*kernel_trace.csv", recursive=True)[0]
+cands = [p] if os.path.isfile(p) else glob.glob(p + "/**/*kernel_trace.csv", recursive=True) + glob.glob(p + "/**/*.db", recursive=True)
+f = cands[0]
 rows = []
-for r in csv.DictReader(open(f)):
-    name = re.sub(r"^void ", "", r["Kernel_Name"])
-    name = re.sub(r"\(.*", "", name).replace("cafe::", "")
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), name, int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))))
+
+
+def clean(name):
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*", "", name).replace("cafe::", "")
+
+
+if f.endswith(".db"):       # rocprofv3's rocpd (sqlite) output
+    import sqlite3
+    for name, q, s, e, gx, wx in sqlite3.connect(f).execute("select name, queue_id, start, end, grid_x, workgroup_x from kernels"):
+        rows.append((int(s), int(e), int(q), clean(name), int(gx) // max(1, int(wx))))
+else:
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), clean(r["Kernel_Name"]),
+                     int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))))
 rows.sort()
 starts = [i for i, r in enumerate(rows) if r[3].startswith("k_forward")]
 if len(starts) < 3:
