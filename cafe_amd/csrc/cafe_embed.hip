@@ -5,11 +5,16 @@
 #include <cstring>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "cafe_internal.h"
 
 using namespace cafe;
+
+static inline double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // ------------------------------------------------------------------------------------------------
 // Scratch of cafe_scores_noalloc_dev: the per-lookup gradient norms that cafe_scores_dev keeps in a workspace it
@@ -66,23 +71,29 @@ extern "C" int cafe_tables_create(cafe_tables_t **out, int num_fields, int dim, 
 
 extern "C" int cafe_tables_set_timing(cafe_tables_t *t, int on) {
     if (on && !t->ev_t[0][0])
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 5; ++k)
             for (int j = 0; j < 2; ++j) CAFE_HIP_CHECK(hipEventCreate(&t->ev_t[k][j]));
     t->timing = on ? 1 : 0;
     return 0;
 }
 
 extern "C" int cafe_tables_kernel_ms(cafe_tables_t *t, int which, float *ms) {
-    if (which < 0 || which > 3 || !t->ev_t[which][0]) { set_error("cafe_tables_kernel_ms: timing was not enabled"); return 1; }
+    if (which < 0 || which > 4 || !t->ev_t[which][0]) { set_error("cafe_tables_kernel_ms: timing was not enabled"); return 1; }
     CAFE_HIP_CHECK(hipEventSynchronize(t->ev_t[which][1]));
     CAFE_HIP_CHECK(hipEventElapsedTime(ms, t->ev_t[which][0], t->ev_t[which][1]));
+    return 0;
+}
+
+// diagnostics: host time spent enqueueing (forward, update) and waiting for the verdict, microseconds per fused step
+extern "C" int cafe_debug_host_times(cafe_sketch_t *s, double *out4) {
+    for (int i = 0; i < 4; ++i) { out4[i] = s->host_us[i]; s->host_us[i] = 0; }
     return 0;
 }
 
 extern "C" int cafe_tables_destroy(cafe_tables_t *t) {
     if (!t) return 0;
     (void)hipDeviceSynchronize();
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 5; ++k)
         for (int j = 0; j < 2; ++j)
             if (t->ev_t[k][j]) (void)hipEventDestroy(t->ev_t[k][j]);
     if (t->ev_plan) (void)hipEventDestroy(t->ev_plan);
@@ -188,6 +199,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
                           hipStream_t st) {
     if (total_l == 0) return 0;
     if (batch <= 0 || total_l < 0 || total_l > 0x7fffffffL / 4) { set_error("cafe forward: bad size %ld", total_l); return 1; }
+    const double t_begin = now_us();
     const int total = (int)total_l;
     const int lpg = lanes_per_row(t->dim);
     const int blocks = (int)std::min<long>(((long)total + 255) / 256, 256 * 16);      // a wave per 64 lookups
@@ -228,6 +240,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     if (plan) {
         if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream)) return 1;
     }
+    s->host_us[0] += now_us() - t_begin;
     return 0;
 }
 
@@ -566,20 +579,28 @@ __device__ inline uint32_t row_key(const int32_t *__restrict__ fields, const int
     return (uint32_t)hotn + (uint32_t)cold_base[f] + (uint32_t)q % (uint32_t)hash_size[f];
 }
 
-// Partition the lookups by table row (key % P): every row's gradients meet in one workgroup, so closed segments are
+// partitions [0, Ph) take hot-table rows, [Ph, Ph + Pc) cold-table rows: the hot half of the update does not depend on
+// the sketch insert or the migration (a slot handed out during a batch was free when the forward ran, so no gradient of
+// this step addresses it), and can run beside them
+__device__ inline uint32_t bwd_part(uint32_t k, uint32_t hotn, uint32_t Ph, uint32_t Pc) {
+    return k < hotn ? k % Ph : Ph + (k - hotn) % Pc;
+}
+
+// Partition the lookups by table row: every row's gradients meet in one workgroup, so closed segments are
 // updated with a plain read-modify-write and nothing needs a device-wide sort.
-__global__ void __launch_bounds__(1024) k_bwd_assign(int P, const int32_t *__restrict__ fields, const int32_t *__restrict__ que,
+__global__ void __launch_bounds__(1024) k_bwd_assign(int Ph, int Pc, const int32_t *__restrict__ fields, const int32_t *__restrict__ que,
                                                      const int32_t *__restrict__ hash_size, const int64_t *__restrict__ cold_base,
                                                      int hotn, int batch, int total, uint32_t *__restrict__ cnt,
                                                      uint32_t *__restrict__ rank, uint32_t *__restrict__ keys) {
     extern __shared__ uint32_t hist[];
+    const int P = Ph + Pc;
     for (int b = threadIdx.x; b < P; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     const int begin = blockIdx.x * kBwdChunk, end = min(begin + kBwdChunk, total);
     for (int i = begin + threadIdx.x; i < end; i += blockDim.x) {
         const uint32_t k = row_key(fields, que, hash_size, cold_base, hotn, batch, i);
         keys[i] = k;
-        rank[i] = atomicAdd(&hist[k % (uint32_t)P], 1u);
+        rank[i] = atomicAdd(&hist[bwd_part(k, (uint32_t)hotn, (uint32_t)Ph, (uint32_t)Pc)], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < P; b += blockDim.x) {
@@ -587,12 +608,12 @@ __global__ void __launch_bounds__(1024) k_bwd_assign(int P, const int32_t *__res
         if (c) hist[b] = atomicAdd(&cnt[b], c);
     }
     __syncthreads();
-    for (int i = begin + threadIdx.x; i < end; i += blockDim.x) rank[i] += hist[keys[i] % (uint32_t)P];
+    for (int i = begin + threadIdx.x; i < end; i += blockDim.x) rank[i] += hist[bwd_part(keys[i], (uint32_t)hotn, (uint32_t)Ph, (uint32_t)Pc)];
 }
 
 // offsets of the partitions, and the list of (partition, tile) work items: one workgroup per <= kBwdCap pairs
-__global__ void __launch_bounds__(1024) k_bwd_offsets(int P, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off,
-                                                      uint32_t *__restrict__ tiles /* [0] = count, then (p << 8 | t)... */) {
+__global__ void __launch_bounds__(1024) k_bwd_offsets(int Ph, int P, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off,
+                                                      uint32_t *__restrict__ tiles /* [0] = hot tiles, [1] = all tiles, then (p << 8 | t)... */) {
     __shared__ uint32_t sh[1024], sh2[1024];
     __shared__ uint32_t carry, carry2;
     if (threadIdx.x == 0) { carry = 0; carry2 = 0; }
@@ -613,22 +634,23 @@ __global__ void __launch_bounds__(1024) k_bwd_offsets(int P, const uint32_t *__r
         if (i < P) {
             off[i] = carry + sh[threadIdx.x] - v;
             const uint32_t t0 = carry2 + sh2[threadIdx.x] - nt;
-            for (uint32_t t = 0; t < nt; ++t) tiles[1 + t0 + t] = ((uint32_t)i << 8) | t;
+            for (uint32_t t = 0; t < nt; ++t) tiles[2 + t0 + t] = ((uint32_t)i << 8) | t;
+            if (i == Ph - 1) tiles[0] = t0 + nt;
         }
         __syncthreads();
         if (threadIdx.x == 1023) { carry += sh[1023]; carry2 += sh2[1023]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { off[P] = carry; tiles[0] = carry2; }
+    if (threadIdx.x == 0) { off[P] = carry; tiles[1] = carry2; }
 }
 
-__global__ void k_bwd_scatter(int P, int total, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ rank,
+__global__ void k_bwd_scatter(int Ph, int Pc, int hotn, int total, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ rank,
                               const uint32_t *__restrict__ off, uint32_t *__restrict__ cnt, unsigned long long *__restrict__ items) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P) cnt[i] = 0;                       // ready for the next call (k_bwd_offsets has consumed it)
+    if (i < Ph + Pc) cnt[i] = 0;                 // ready for the next call (k_bwd_offsets has consumed it)
     if (i >= total) return;
     const uint32_t k = keys[i];
-    items[off[k % (uint32_t)P] + rank[i]] = ((unsigned long long)k << 32) | (uint32_t)i;
+    items[off[bwd_part(k, (uint32_t)hotn, (uint32_t)Ph, (uint32_t)Pc)] + rank[i]] = ((unsigned long long)k << 32) | (uint32_t)i;
 }
 
 __device__ inline float *row_ptr(uint32_t key, uint32_t item, const int32_t *__restrict__ fields, float *__restrict__ w_hot,
@@ -680,12 +702,13 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
     __shared__ float4 bpart[2][VPL][256];      // border partial sums: [0] head of a group's range, [1] tail
     __shared__ int bflag[256];
     const int tid = threadIdx.x;
-    if (blockIdx.x >= tiles[0]) return;
+    const uint32_t tile_at = blockIdx.x;
+    if (tile_at >= tiles[1]) return;
     // queued behind an insert whose verdict the host has not seen yet: if the device rejected it (DevState::fallback
     // == 2) the host issues the step again, and this update with it
     if (skip_if_2 && *skip_if_2 == 2) return;
     // the tile index is kept in 8 bits; a partition with more tiles lets its last workgroup walk the rest
-    const uint32_t tl = tiles[1 + blockIdx.x];
+    const uint32_t tl = tiles[2 + tile_at];
     const int p = (int)(tl >> 8), tile = (int)(tl & 255u);
     const uint32_t o0 = off[p];
     const int cnt = (int)(off[p + 1] - o0);
@@ -839,8 +862,8 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
     BWD_STAMP(2);
 }
 
-// The backward in two parts: the partition passes (they read the routing only) on `pst`, the segment kernel (gradient
-// rows in, table rows updated) on `st`.  With pst != st the caller orders st behind t->ev_plan, recorded here on pst.
+// The backward in two parts: 1 the partition passes (they read the routing only) on `pst`, 2 the segment kernel (gradient
+// rows in, table rows updated) on `st`, ordered behind t->ev_plan (recorded here on pst) when the streams differ.
 static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,
                            int batch, int total, float lr, hipStream_t st, hipStream_t pst, int part = 3,
                            const int32_t *skip_if_2 = nullptr) {
@@ -850,12 +873,13 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     const int lpg = lanes_per_row(t->dim);
     const int vpl = (t->dim / 4 + lpg - 1) / lpg;
     if (vpl > 4) { set_error("cafe_backward_sgd_dev: dim %d too large", t->dim); return 1; }
-    int P = std::max(1, std::min((total + kBwdTarget - 1) / kBwdTarget, kBwdMaxBins));
+    // each half is sized for 60 % of the lookups
+    const int Ph = std::max(1, std::min(((total * 3 / 5) + kBwdTarget - 1) / kBwdTarget, kBwdMaxBins / 2)), Pc = Ph, P = Ph + Pc;
     const size_t cnt_bytes = 4 * (size_t)kBwdMaxBins + 16;
     // partition counters: zero from the allocation (DevBuf::reserve), kept zero by the scatter pass
     if (t->ws_bwd_a.reserve(cnt_bytes)) return 1;
     const int max_tiles = P + total / kBwdCap + 1;
-    if (t->ws_bwd_b.reserve(4 * (size_t)kBwdMaxBins + 16) || t->ws_norm.reserve(0) || t->ws_misc.reserve(4 * (size_t)max_tiles + 16) ||
+    if (t->ws_bwd_b.reserve(4 * (size_t)kBwdMaxBins + 16) || t->ws_misc.reserve(4 * (size_t)max_tiles + 32) ||
         t->ws_bwd_c.reserve(8 * (size_t)total) ||
         t->ws_bwd_d.reserve(8 * (size_t)total)) return 1;
     uint32_t *cnt = t->ws_bwd_a.as<uint32_t>(), *off = t->ws_bwd_b.as<uint32_t>();
@@ -863,10 +887,10 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     unsigned long long *items = t->ws_bwd_d.as<unsigned long long>();
     uint32_t *tiles = t->ws_misc.as<uint32_t>();
     if (part & 1) {
-        hipLaunchKernelGGL(k_bwd_assign, dim3((total + kBwdChunk - 1) / kBwdChunk), dim3(1024), 4 * (size_t)P, pst, P, d_fields,
+        hipLaunchKernelGGL(k_bwd_assign, dim3((total + kBwdChunk - 1) / kBwdChunk), dim3(1024), 4 * (size_t)P, pst, Ph, Pc, d_fields,
                            d_que, t->d_hash_size, t->d_cold_base, t->hotn, batch, total, cnt, rank, keys);
-        hipLaunchKernelGGL(k_bwd_offsets, dim3(1), dim3(1024), 0, pst, P, cnt, off, tiles);
-        hipLaunchKernelGGL(k_bwd_scatter, dim3((std::max(total, P) + 255) / 256), dim3(256), 0, pst, P, total, keys, rank, off,
+        hipLaunchKernelGGL(k_bwd_offsets, dim3(1), dim3(1024), 0, pst, Ph, P, cnt, off, tiles);
+        hipLaunchKernelGGL(k_bwd_scatter, dim3((std::max(total, P) + 255) / 256), dim3(256), 0, pst, Ph, Pc, t->hotn, total, keys, rank, off,
                            cnt, items);
         if (pst != st) {
             if (!t->ev_plan) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_plan, hipEventDisableTiming));
@@ -875,10 +899,12 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     }
     if (!(part & 2)) { CAFE_HIP_CHECK(hipGetLastError()); return 0; }
     if (pst != st) CAFE_HIP_CHECK(hipStreamWaitEvent(st, t->ev_plan, 0));
+    const int grid = max_tiles;
 #define CAFE_SEG(L, V)                                                                                                   \
-    hipLaunchKernelGGL((k_bwd_segments<L, V>), dim3(max_tiles), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
+    hipLaunchKernelGGL((k_bwd_segments<L, V>), dim3(grid), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
                        t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_if_2)
-    if (t->timing) (void)hipEventRecord(t->ev_t[1][0], st);
+    const int tk = 1;
+    if (t->timing) (void)hipEventRecord(t->ev_t[tk][0], st);
     if (vpl == 1) {
         switch (lpg) {
             case 1: CAFE_SEG(1, 1); break;
@@ -895,7 +921,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         CAFE_SEG(64, 4);
     }
 #undef CAFE_SEG
-    if (t->timing) (void)hipEventRecord(t->ev_t[1][1], st);
+    if (t->timing) (void)hipEventRecord(t->ev_t[tk][1], st);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -943,6 +969,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
         }
         if (cadence && !cafe::threshold_known_above_one(s)) fuse = false;
     }
+    const double t_begin = now_us();
     if (fuse) {
         // What does not depend on this step's gradients runs on the sketch's second stream, beside the norm kernel: the
         // plan of the insert (ids and pre-batch tables only) and the partition passes of the backward (routing of the
@@ -982,6 +1009,9 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             s->ev_chain[0] = s->ev_chain[1] = nullptr;
             if (rc) return 1;
             if (side != st && !plan_done) {
+                // the partition passes of the update (they read the routing only) beside the insert.  (The update itself
+                // stays behind the migration: run beside the insert it slowed the insert's latency-bound kernels by
+                // more than it saved, and hot rows are not disjoint from migration targets after a reset.)
                 if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 1)) return 1;
                 plan_done = true;
             }
@@ -990,7 +1020,9 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
                                 &s->d_state->fallback)) return 1;
             bool rejected = false;
             int reason = 0;
+            const double t_wait = now_us();
             if (cafe::last_insert_verdict(s, &rejected, &reason)) return 1;
+            s->host_us[1] += t_wait - t_begin; s->host_us[2] += now_us() - t_wait; s->host_us[3] += 1;
             if (!rejected) { s->force_cap_once = 0; return 0; }
             // nothing was applied on the device: take the call counters back as well
             s->decay = decay0;

@@ -46,7 +46,9 @@ constexpr int kChunk = 2048;          // ids per plan workgroup
 constexpr int kPlanThreads = 512;     // 8 waves, 256 consecutive ids each
 constexpr int kPlanWaves = kPlanThreads / 64;
 constexpr int kPlanRows = kChunk / kPlanThreads;     // rows of 64 ids a plan wave walks
-constexpr int kMaxParts = 2048;       // partitions per table: 3 P1 + P2 <= 8192 bins of the plan histogram (LDS: 8 waves x 8192 x 2 B)
+constexpr int kMaxParts = 2048;       // partitions per table: 2 P1 + P2 + PH <= 8192 bins of the plan histogram (LDS: 8 waves x 8192 x 2 B)
+constexpr int kMaxPlanBins = 8192;
+constexpr int kHotKeys = 1024;        // slots (4 per bucket) of a hot partition that fit the per-wave LDS table
 constexpr int kCapEv = 512;           // moves one main partition can receive per round
 constexpr int kCapEvL = 1024;         // moves one LRU partition can emit per round (an item emits at most one)
 constexpr int kMaxRounds = 16;
@@ -108,8 +110,10 @@ struct ParWorkspace {
 struct Geo {
     int n, n1, n2, P1, P2, bpp1, bpp2;
     int bits1, bits2;           // bits of a bucket index inside a main / LRU partition
-    int nchunks, nbins;         // plan geometry: nbins = 3 P1 + P2
+    int nchunks, nbins;         // plan geometry: nbins = 2 P1 + P2 + PH
     int hot;                    // 1: ids that sit hot in the main table before the batch bypass the owner rounds
+    int PH, bpph, bitsh;        // hot list: partitions, buckets per partition, bits of a bucket index inside one
+    int hot_table;              // 1: a hot partition's slots fit the per-wave LDS table (no sort; one wave per partition)
     uint32_t gflip;             // flip bit of this call (known on the host)
     int flip_now;               // sketch.cpp:286-288 happen in this call
     int seg;                    // > 0: ids per reference call when this call stands for several (cafe_backward_update_dev)
@@ -123,10 +127,10 @@ struct Geo {
 };
 
 // bins of the plan histogram: [0, 2 P1) main partitions, class C at 2p, class M at 2p + 1; [2 P1, 2 P1 + P2) LRU
-// partitions; [2 P1 + P2, 3 P1 + P2) hot partitions
+// partitions; [2 P1 + P2, 2 P1 + P2 + PH) hot partitions
 __device__ __host__ inline int bin_lru0(const Geo &g) { return 2 * g.P1; }
 __device__ __host__ inline int bin_hot0(const Geo &g) { return 2 * g.P1 + g.P2; }
-// offsets: one array, [0 .. 2 P1] main list, then [0 .. P2] LRU list, then [0 .. P1] hot list (each list starts at 0)
+// offsets: one array, [0 .. 2 P1] main list, then [0 .. P2] LRU list, then [0 .. PH] hot list (each list starts at 0)
 __device__ __host__ inline int off_lru0(const Geo &g) { return 2 * g.P1 + 1; }
 __device__ __host__ inline int off_hot0(const Geo &g) { return 2 * g.P1 + 1 + g.P2 + 1; }
 
@@ -239,7 +243,7 @@ __global__ void __launch_bounds__(kPlanThreads) k_assign(Geo g, const MainBucket
             const bool hot = slot >= 0 && dic != 0;
             const int p1 = b1 / g.bpp1;
             if (g.hot && hot && !pending) {
-                binA = (uint32_t)(bin_hot0(g) + p1);
+                binA = (uint32_t)(bin_hot0(g) + b1 / g.bpph);
                 extra = (uint32_t)slot << 24;
             } else {
                 const bool c = pending || slot >= 0;         // the bucket has to be replayed in round 1
@@ -350,7 +354,7 @@ __global__ void __launch_bounds__(kThreads) k_offsets(Geo g, const uint16_t *__r
     uint32_t over = 0, maxpart = 0, maxhot = 0, nclassc = 0;
     for (int list = 0; list < 3; ++list) {
         const int b0 = list == 0 ? 0 : list == 1 ? bin_lru0(g) : bin_hot0(g);
-        const int cnt = list == 0 ? 2 * g.P1 : list == 1 ? g.P2 : g.P1;
+        const int cnt = list == 0 ? 2 * g.P1 : list == 1 ? g.P2 : g.PH;
         uint32_t *o = off + (list == 0 ? 0 : list == 1 ? off_lru0(g) : off_hot0(g));
         if (tid == 0) carry = 0;
         __syncthreads();
@@ -429,9 +433,9 @@ __global__ void __launch_bounds__(256) k_scatter(Geo g, IdSrc ids, const uint32_
     Rec r;
     r.pos = (uint32_t)i; r.x = x; r.pad = 0;
     if (binA >= bin_hot0(g)) {
-        const int p1 = binA - bin_hot0(g);
-        r.bl = ((uint32_t)(h1 - p1 * g.bpp1) << 2) | ((a >> 24) & 3u);
-        rech[off[off_hot0(g) + p1] + rankA] = r;
+        const int ph = binA - bin_hot0(g);
+        r.bl = ((uint32_t)(h1 - ph * g.bpph) << 2) | ((a >> 24) & 3u);
+        rech[off[off_hot0(g) + ph] + rankA] = r;
         miss[i] = 0;
         return;
     }
@@ -595,13 +599,13 @@ __device__ inline void hot_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy,
     if (tid == 0) *n_heavy = 0;
     CAFE_STAMP_VAL(g.prof, 7, 1ull | ((unsigned long long)total << 8));
     field_sums(g, sc, fsum);
-    const int b0 = p * g.bpp1;
+    const int b0 = p * g.bpph;
     const Rec *recs = rech + o0;
     if (total > 512) __builtin_amdgcn_s_setprio(3);
     for (int j = tid; j < total; j += kThreads) L.t.grp[j] = recs[j].bl;
     __syncthreads();
     CAFE_STAMP(g.prof, 1);
-    lsd_sort<CAP, MV>(L.t, total, g.bits1 + 2, false);
+    lsd_sort<CAP, MV>(L.t, total, g.bitsh + 2, false);
     CAFE_STAMP(g.prof, 2);
     constexpr int IPT = CAP / kThreads;
     uint16_t myr[IPT];
@@ -726,26 +730,132 @@ __device__ inline void hot_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy,
     }
 }
 
-// Score of hot slot `slot` of bucket `bl` (partition-local) as a move at `time` sees it: the running score behind the
-// slot's last bypassed item before `time`, or `base` (the table's value) if there is none.
-__device__ inline float hot_cnt_at(const unsigned long long *__restrict__ hk, const float *__restrict__ hr, int nh,
-                                   uint32_t bl, int slot, uint32_t time, float base) {
-    const unsigned long long target = ((unsigned long long)((bl << 2) | (uint32_t)slot) << 23) | time;   // in units of key >> 16
-    int lo = 0, hi = nh;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((hk[mid] >> 16) < target) lo = mid + 1; else hi = mid;
+// ---- the same without a sort: a wave per hot partition ------------------------------------------------------------
+// The slots of a small hot partition (4 per bucket, <= kHotKeys) get one accumulator each in an LDS table of the wave.
+// The wave walks the partition's items row by row (64 at a time, batch order); the items of a row that address the same
+// slot are found by ballots and added, in lane order, by the first of them.  No sort, no workgroup barrier, no limit
+// on the items of a partition.  Outputs as hot_owner's, in batch order (hfin at every item: commit writes the same
+// final score several times).
+__device__ inline void hot_table_owner(float *acc /* [kHotKeys] */, float *runs /* [64] */, const float *fsum, const Geo &g, int ph,
+                                       const MainBucket *__restrict__ mt, const DevState *__restrict__ st,
+                                       const uint32_t *__restrict__ off, const Rec *__restrict__ rech, const Score &sc,
+                                       unsigned long long *__restrict__ hkey, float *__restrict__ hrun, int2 *__restrict__ hfin,
+                                       uint8_t *__restrict__ outm) {
+    (void)runs;
+    const int lane = threadIdx.x & 63;
+    const uint32_t o0 = off[off_hot0(g) + ph], o1 = off[off_hot0(g) + ph + 1];
+    const int total = (int)(o1 - o0);
+    if (total == 0) return;
+    const int b0 = ph * g.bpph;
+    const Rec *recs = rech + o0;
+    const ScoreSrc ss = score_src(g, sc, fsum);
+    const unsigned long long below = lanes_below();
+    const float thr = st->thr;
+    // a partition with a heavy id is a long chain of dependent adds in ONE wave, and round 1 ends when the longest chain
+    // does: that wave issues ahead of the others on its SIMD
+    if (total > 96) __builtin_amdgcn_s_setprio(3);
+    constexpr int R = 4;             // rows of 64 items whose records and scores are requested together
+    // the table's score of every slot that has items (items of one slot write the same value); the first R rows are
+    // covered by the main loop's own loads
+    for (int j = R * 64 + lane; j < total; j += 64) {
+        const uint32_t key = recs[j].bl;
+        acc[key] = mt[b0 + (int)(key >> 2)].cnt[key & 3u];
     }
-    if (lo > 0 && (uint32_t)(hk[lo - 1] >> 39) == ((bl << 2) | (uint32_t)slot)) return hr[lo - 1];
-    return base;
+    for (int cbase = 0; cbase < total; cbase += R * 64) {
+        Rec rr[R];
+        float cc[R], base[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) rr[k] = recs[min(cbase + k * 64 + lane, total - 1)];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            cc[k] = ss.at(rr[k].pos);
+            base[k] = cbase == 0 ? mt[b0 + (int)(rr[k].bl >> 2)].cnt[rr[k].bl & 3u] : 0.0f;
+        }
+        if (cbase == 0) {
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if (k * 64 + lane < total) acc[rr[k].bl] = base[k];
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int j = cbase + k * 64 + lane;
+            if (cbase + k * 64 >= total) break;
+            const bool valid = j < total;
+            const uint32_t key = rr[k].bl;
+            const float c = cc[k];
+            const unsigned long long m = match_any(key, g.bitsh + 2, valid);
+            const bool leader = valid && !(m & below);
+            __builtin_amdgcn_wave_barrier();
+            // Slot by slot (the loop is uniform, so a peer's score travels by v_readlane, not through LDS): the slot's
+            // items of this row are added in lane order, every item keeps the score behind it.
+            float a_all = leader ? acc[key] : 0.0f;
+            float run = 0.0f;
+            const int mlo = (int)(uint32_t)m, mhi = (int)(uint32_t)(m >> 32);
+            unsigned long long leaders = __ballot(leader);
+            while (leaders) {
+                const int ll = __builtin_ctzll(leaders);
+                leaders &= leaders - 1ull;
+                unsigned long long rest = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mhi, ll) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane(mlo, ll);
+                float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_all), ll));
+                while (rest) {
+                    const int pl = __builtin_ctzll(rest);
+                    rest &= rest - 1ull;
+                    a += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), pl));
+                    run = lane == pl ? a : run;
+                }
+                a_all = lane == ll ? a : a_all;
+            }
+            if (leader) acc[key] = a_all;
+            if (valid) {
+                hkey[o0 + j] = ((unsigned long long)key << 39) | ((unsigned long long)(2u * rr[k].pos) << 16);
+                hrun[o0 + j] = run;
+                outm[rr[k].pos] = (run >= thr && run - c < thr) ? oCross : 0;         // sketch.cpp:218-220
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (total <= R * 64) {
+            // the usual case: the whole partition was in registers
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int j = k * 64 + lane;
+                if (j < total) hfin[o0 + j] = make_int2((b0 + (int)(rr[k].bl >> 2)) * 4 + (int)(rr[k].bl & 3u), __float_as_int(acc[rr[k].bl]));
+            }
+            return;
+        }
+    }
+    for (int j = lane; j < total; j += 64) {
+        const uint32_t key = recs[j].bl;
+        hfin[o0 + j] = make_int2((b0 + (int)(key >> 2)) * 4 + (int)(key & 3u), __float_as_int(acc[key]));
+    }
 }
-__device__ inline void patch_hot(MainR &b, const unsigned long long *__restrict__ hk, const float *__restrict__ hr, int nh,
-                                 uint32_t bl, uint32_t time) {
+
+// Score of hot slot `key` (bucket in hot partition << 2 | slot) as a move at `time` sees it: the running score behind
+// the slot's last bypassed item before `time`, or `base` (the table's value) if there is none.  The partition's items
+// are in batch order, or sorted by (slot, time): either way the last match is the latest.  (A handful of moves per batch
+// look here.)
+__device__ inline float hot_cnt_at(const unsigned long long *__restrict__ hk, const float *__restrict__ hr, int nh,
+                                   uint32_t key, uint32_t time, float base) {
+    float best = base;
+    for (int j = 0; j < nh; ++j) {
+        const unsigned long long k = hk[j];
+        if ((uint32_t)(k >> 39) == key && ((uint32_t)(k >> 16) & 0x7fffffu) < time) best = hr[j];
+    }
+    return best;
+}
+// bucket h1 (global index) of the main table
+__device__ inline void patch_hot(MainR &b, const Geo &g, const uint32_t *__restrict__ off, const unsigned long long *__restrict__ hkey,
+                                 const float *__restrict__ hrun, int h1, uint32_t time) {
+    if (!g.hot || !(b.d0 | b.d1 | b.d2 | b.d3)) return;
+    const int ph = h1 / g.bpph;
+    const uint32_t oh0 = off[off_hot0(g) + ph];
+    const int nh = (int)(off[off_hot0(g) + ph + 1] - oh0);
     if (nh <= 0) return;
-    if (b.d0) b.c0 = hot_cnt_at(hk, hr, nh, bl, 0, time, b.c0);
-    if (b.d1) b.c1 = hot_cnt_at(hk, hr, nh, bl, 1, time, b.c1);
-    if (b.d2) b.c2 = hot_cnt_at(hk, hr, nh, bl, 2, time, b.c2);
-    if (b.d3) b.c3 = hot_cnt_at(hk, hr, nh, bl, 3, time, b.c3);
+    const uint32_t kb = (uint32_t)(h1 - ph * g.bpph) << 2;
+    if (b.d0) b.c0 = hot_cnt_at(hkey + oh0, hrun + oh0, nh, kb | 0u, time, b.c0);
+    if (b.d1) b.c1 = hot_cnt_at(hkey + oh0, hrun + oh0, nh, kb | 1u, time, b.c1);
+    if (b.d2) b.c2 = hot_cnt_at(hkey + oh0, hrun + oh0, nh, kb | 2u, time, b.c2);
+    if (b.d3) b.c3 = hot_cnt_at(hkey + oh0, hrun + oh0, nh, kb | 3u, time, b.c3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -833,9 +943,6 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
     field_sums(g, sc, fsum);
     const int b0 = p * g.bpp1;
     const Rec *recs = A.rec1 + o0;
-    // this partition's bypassed hot items, looked at only when a move arrives (it compares all four scores)
-    const uint32_t oh0 = g.hot && ne ? A.off[off_hot0(g) + p] : 0u;
-    const int nhot = g.hot && ne ? (int)(A.off[off_hot0(g) + p + 1] - oh0) : 0;
     if (total > 512) __builtin_amdgcn_s_setprio(3);
 
     // elements: [0, nc) class C items, [nc, np) class M items, [np, total) moves
@@ -949,7 +1056,7 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
                 ctx.pushed = 0;
                 const uint16_t pm = L.s.pm[e];
                 const int32_t dic = A.ev[evbase + (int)(pm & 0x7fffu)].dic;
-                patch_hot(b, A.hkey + oh0, A.hrun + oh0, nhot, bl, time);
+                patch_hot(b, g, A.off, A.hkey, A.hrun, b0 + (int)bl, time);
                 int ok = main_move(b, L.s.px[e], L.s.pc[e], dic, ctx);
                 EvRes r;
                 r.tag = A.call_tag; r.kind = (pm & 0x8000u) ? 1 : 2; r.ok = ok; r.pushed = ctx.pushed; r.pad = 0;
@@ -1065,7 +1172,7 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
                         ctx.pushed = 0;
                         const uint16_t pmv = L.s.pm[e];
                         const int32_t dic = A.ev[evbase + (int)(pmv & 0x7fffu)].dic;
-                        patch_hot(b, A.hkey + oh0, A.hrun + oh0, nhot, bl, time0);
+                        patch_hot(b, g, A.off, A.hkey, A.hrun, b0 + (int)bl, time0);
                         int ok = main_move(b, x0, L.s.pc[e], dic, ctx);
                         if (lane == 0) {
                             EvRes r;
@@ -1263,7 +1370,7 @@ struct HotArgs {
 };
 
 template <int CAP>
-__global__ void __launch_bounds__(kThreads) k_round1(Geo g, MainArgs MA, LruArgs LA, HotArgs HA, Score sc) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CAP <= 1024 ? 8 : 1, 8))) k_round1(Geo g, MainArgs MA, LruArgs LA, HotArgs HA, Score sc) {
     __shared__ __attribute__((aligned(16))) OwnerLds<CAP, false> L;
     __shared__ int heavy[kMaxHeavy];
     __shared__ int n_heavy, s_total;
@@ -1273,9 +1380,22 @@ __global__ void __launch_bounds__(kThreads) k_round1(Geo g, MainArgs MA, LruArgs
     CAFE_STAMP_VAL(0, 7, 0ull);
     CAFE_STAMP(0, 0);
     int b = blockIdx.x;
-    const int nhot = g.hot ? g.P1 : 0;
+    const int nhot = !g.hot ? 0 : g.hot_table ? (g.PH + kWaves - 1) / kWaves : g.PH;
     if (b < nhot) {
-        hot_owner<CAP, false>(L, heavy, &n_heavy, fsum, g, b, MA.mt, MA.st, MA.ctl, MA.off, HA.rech, sc, HA.hkey, HA.hrun, HA.hfin, MA.outm);
+        if (g.hot_table) {
+            // a wave per hot partition; the waves share nothing but the field sums
+            field_sums(g, sc, fsum);
+            __syncthreads();
+            float *tab = reinterpret_cast<float *>(&L);
+            const int wave = threadIdx.x >> 6, ph = b * kWaves + wave;
+            static_assert(sizeof(L) >= kWaves * (kHotKeys + 64) * sizeof(float), "hot table");
+            CAFE_STAMP_VAL(0, 7, 1ull);
+            if (ph < g.PH)
+                hot_table_owner(tab + wave * (kHotKeys + 64), tab + wave * (kHotKeys + 64) + kHotKeys, fsum, g, ph, MA.mt, MA.st, MA.off,
+                                HA.rech, sc, HA.hkey, HA.hrun, HA.hfin, MA.outm);
+        } else {
+            hot_owner<CAP, false>(L, heavy, &n_heavy, fsum, g, b, MA.mt, MA.st, MA.ctl, MA.off, HA.rech, sc, HA.hkey, HA.hrun, HA.hfin, MA.outm);
+        }
         CAFE_STAMP(0, 6);
         return;
     }
@@ -1547,8 +1667,21 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
     const uint32_t head = st->fifo_head, len0 = st->fifo_len;
     const int32_t clk0 = st->clk;
     if (verdict == 0) {
-        const int nparts = g.P1 + g.P2;
+        const int nparts = g.P1 + g.P2 + (g.hot ? g.PH : 0);
+        const uint32_t gflip = (uint32_t)st->flip;
         for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
+            if (part >= g.P1 + g.P2) {
+                // final scores of the bypassed hot slots of one hot partition
+                const int ph = part - g.P1 - g.P2;
+                const uint32_t oh0 = A.off[off_hot0(g) + ph];
+                const int nh = (int)(A.off[off_hot0(g) + ph + 1] - oh0);
+                for (int s = tid; s < nh; s += blockDim.x) {
+                    const int2 f = A.hfin[oh0 + s];
+                    if (f.x >= 0 && (f.x >> 2) >= g.n1) { atomicAdd(&st->bad_commit, 1); continue; }
+                    if (f.x >= 0) A.mt[f.x >> 2].cnt[f.x & 3] = __int_as_float(f.y);
+                }
+                continue;
+            }
             int tot = (int)A.stage_tot[part];
             // Everything below indexes the tables with numbers read from the staging buffers.  They are written by the
             // owners of this very call; the range checks turn a broken invariant into a counted refusal, not a wild store.
@@ -1566,23 +1699,25 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
                     d.x = resolve_dic(d.x, A.fifo, A.cap, head, A.poprank, (uint32_t)g.n); d.y = resolve_dic(d.y, A.fifo, A.cap, head, A.poprank, (uint32_t)g.n);
                     d.z = resolve_dic(d.z, A.fifo, A.cap, head, A.poprank, (uint32_t)g.n); d.w = resolve_dic(d.w, A.fifo, A.cap, head, A.poprank, (uint32_t)g.n);
                     int4 *o = reinterpret_cast<int4 *>(&A.mt[m.y]);
-                    o[0] = v; o[1] = d; o[2] = c;
-                    A.mt[m.y].flip = (uint32_t)m.x;
-                }
-                if (g.hot) {
-                    // final scores of the bypassed hot slots of this partition, behind its staged buckets (which carry
-                    // the pre-batch score in those slots)
-                    const uint32_t oh0 = A.off[off_hot0(g) + part];
-                    const int nh = (int)(A.off[off_hot0(g) + part + 1] - oh0);
-                    // both writers are waves of this workgroup (one CU, one L2): once the staged stores are acknowledged,
-                    // later stores to the same words land behind them
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    for (int s = tid; s < nh; s += blockDim.x) {
-                        const int2 f = A.hfin[oh0 + s];
-                        if (f.x >= 0 && (f.x >> 2) >= g.n1) { atomicAdd(&st->bad_commit, 1); continue; }
-                        if (f.x >= 0) A.mt[f.x >> 2].cnt[f.x & 3] = __int_as_float(f.y);
+                    // A slot that was hot before the batch, in a bucket without a pending decay, went through the bypass:
+                    // its score is written by the hot partition's workgroup (above) -- at any time, so the staged copy's
+                    // stale score must not be stored over it, not even as part of a wider store.
+                    bool k0 = false, k1 = false, k2 = false, k3 = false;
+                    if (g.hot && A.mt[m.y].flip == gflip) {
+                        const int4 told = o[1];
+                        k0 = told.x != 0; k1 = told.y != 0; k2 = told.z != 0; k3 = told.w != 0;
                     }
+                    o[0] = v; o[1] = d;
+                    if (!(k0 | k1 | k2 | k3)) {
+                        o[2] = c;
+                    } else {
+                        int32_t *oc = reinterpret_cast<int32_t *>(&o[2]);
+                        if (!k0) oc[0] = c.x;
+                        if (!k1) oc[1] = c.y;
+                        if (!k2) oc[2] = c.z;
+                        if (!k3) oc[3] = c.w;
+                    }
+                    A.mt[m.y].flip = (uint32_t)m.x;
                 }
             } else {
                 const LruBucket *stage = A.stage_l + A.off[off_lru0(g) + (part - g.P1)];
@@ -1715,10 +1850,18 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     g.bits1 = ilog2_ceil(g.bpp1);
     g.bits2 = ilog2_ceil(g.bpp2);
     g.nchunks = (n + kChunk - 1) / kChunk;
-    g.nbins = 3 * g.P1 + g.P2;
+    // hot list: partitions small enough for the per-wave slot table if the plan's histogram has room for them, else
+    // the main table's partitions (sorted by the owner)
+    g.hot = s->opt_hot_bypass ? 1 : 0;
+    const int ph_table = (s->n1 + kHotKeys / 4 - 1) / (kHotKeys / 4);
+    g.hot_table = g.hot && s->opt_hot_table && ph_table + 2 * g.P1 + g.P2 <= kMaxPlanBins;
+    g.PH = g.hot_table ? ph_table : g.P1;
+    g.bpph = (s->n1 + g.PH - 1) / g.PH;
+    g.PH = (s->n1 + g.bpph - 1) / g.bpph;
+    g.bitsh = ilog2_ceil(g.bpph);
+    g.nbins = 2 * g.P1 + g.P2 + g.PH;
     const size_t N = (size_t)n, PP = (size_t)g.P1 + g.P2;
     const int nblocks = (n + kScanBlock - 1) / kScanBlock;
-    g.hot = s->opt_hot_bypass ? 1 : 0;
     g.gflip = (uint32_t)s->flip;
     g.seg = s->seg_len > 0 && (n + s->seg_len - 1) / s->seg_len <= kMaxSeg ? s->seg_len : 0;
     g.verify = s->verify_mode ? 1 : 0;
@@ -1760,7 +1903,7 @@ static int pick_cap(cafe_sketch *s, int n) {
     if (s->force_cap) return s->force_cap;
     const Mirror *m = reinterpret_cast<const Mirror *>(s->h_pinned);
     if (s->last_seen_batch != n || m->seq == 0) { s->last_seen_batch = n; return 2048; }
-    const long big = std::max(m->st.maxpart, m->st.pad[3]);
+    const long big = std::max(m->st.maxpart, s->opt_hot_table ? 0 : m->st.pad[3]);       // (hot partitions of the table form have no limit)
     if (m->st.fallback) return 8192;
     if (big + big / 8 + 32 <= 1024) return 1024;
     if (big + big / 8 + 32 <= 2048) return 2048;
@@ -1858,7 +2001,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     HA.rech = rech; HA.hkey = w.hkey.as<unsigned long long>(); HA.hrun = w.hrun.as<float>(); HA.hfin = w.hfin.as<int2>();
     const int cap = pick_cap(s, n);
     if (s->ev_chain[0]) (void)hipEventRecord(s->ev_chain[0], st);
-    const int grid1 = (g.hot ? g.P1 : 0) + g.P2 + g.P1;
+    const int grid1 = (!g.hot ? 0 : g.hot_table ? (g.PH + kWaves - 1) / kWaves : g.PH) + g.P2 + g.P1;
     if (cap == 1024) {
         hipLaunchKernelGGL((k_round1<1024>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
         hipLaunchKernelGGL((k_fix<2048>), dim3(kFixGrid), dim3(kThreads), 0, st, g, MA, LA, sc);
@@ -1885,7 +2028,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     CA.mirror = reinterpret_cast<Mirror *>(s->d_pinned); CA.seq = s->call_seq;
     CA.reset_at = s->adjust ? s->lim * 1.2 : 1e300;
     CA.gotcount = w.ctl.as<uint32_t>() + kCtlWords + 2 * (size_t)kMaxParts + 4;
-    const int cb = g.P1 + g.P2;
+    const int cb = g.P1 + g.P2 + (g.hot ? g.PH : 0);
     hipLaunchKernelGGL(k_commit, dim3(cb), dim3(256), 0, st, g, CA, sc);
     if (s->ev_chain[1]) (void)hipEventRecord(s->ev_chain[1], st);
     CAFE_HIP_CHECK(hipGetLastError());

@@ -48,7 +48,7 @@ struct cafe_sketch {
     uint32_t fifo_cap = 1;
     cafe::DevState *d_state = nullptr;
     // options / counters
-    int opt_serial = 0, opt_max_rounds = 6, opt_target_items = 320, opt_hot_bypass = 1;
+    int opt_serial = 0, opt_max_rounds = 6, opt_target_items = 320, opt_hot_bypass = 1, opt_hot_table = 0;
     int force_cap = 0;                  // option "owner_cap": items an owner workgroup can hold (0 = chosen per call)
     int force_cap_once = 0;             // ... for the call being issued (a step issued again after a workspace limit)
     int score_seg = 0;                  // > 0: vals are norms, scaled per segment of score_seg ids (ScoreSrc)
@@ -72,6 +72,7 @@ struct cafe_sketch {
     uint32_t plan_seq = 0;
     const void *plan_ids = nullptr, *plan_expect = nullptr;   // plan_expect: the ids of the insert being issued
     int opt_plan_ahead = 1, unused_plans = 0;
+    double host_us[4] = {0, 0, 0, 0};   // diagnostics (cafe_debug_host_times)
     long long counters_plan_ahead = 0;
     hipEvent_t ev_done = nullptr;       // recorded behind the closing kernel of every insert
     int ev_done_valid = 0;
@@ -106,7 +107,8 @@ struct cafe_tables {
     // optional HIP-event timing (bench.py's roofline figures): [0] k_forward, [1] k_bwd_segments, [2] the sketch insert
     // (round 1 .. commit), [3] k_grad_norm
     int timing = 0;
-    hipEvent_t ev_t[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    // [4] the hot-table half of k_bwd_segments when it runs on the second stream
+    hipEvent_t ev_t[5][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     hipEvent_t ev_plan = nullptr;    // partition passes of the backward done (recorded on the sketch's side stream)
 };
 

@@ -386,6 +386,7 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
     else if (!strcmp(name, "target_items")) s->opt_target_items = value < 16 ? 16 : value;
     else if (!strcmp(name, "hot_bypass")) s->opt_hot_bypass = value ? 1 : 0;
     else if (!strcmp(name, "exact_reset")) (void)value;          // kept for callers of older builds: the decision is always exact
+    else if (!strcmp(name, "hot_table")) s->opt_hot_table = value ? 1 : 0;
     else if (!strcmp(name, "plan_ahead")) s->opt_plan_ahead = value ? 1 : 0;
     else if (!strcmp(name, "owner_cap")) s->force_cap = value == 1024 || value == 2048 || value == 8192 ? value : 0;
     else if (!strcmp(name, "overlap")) s->opt_overlap = value;

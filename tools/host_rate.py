@@ -22,5 +22,11 @@ for rep in range(3):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
+    import ctypes
+    ht = (ctypes.c_double * 4)()
+    eng.L.cafe_debug_host_times.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    eng.L.cafe_debug_host_times(eng.sketch.h, ht)
+    k = max(ht[3], 1)
+    print(f"   inside the library per step: forward enqueue {ht[0] / k:.1f} us, update enqueue {ht[1] / k:.1f} us, verdict wait {ht[2] / k:.1f} us")
     print(f"{cfg}: host enqueue {1e6 * (t1 - t0) / n:.1f} us/step, total {1e6 * (t2 - t0) / n:.1f} us/step, drain after loop {1e3 * (t2 - t1):.2f} ms", flush=True)
 print(eng.sketch.counters())
