@@ -419,4 +419,41 @@ __device__ inline int32_t median_bucket(const int32_t val[kSlots], const int32_t
     return (int32_t)x;
 }
 
+// 16-byte vector store with sc1: the bytes are written through, no dirty line stays behind in the XCD's L2.  For the
+// bulk outputs of the bandwidth kernels, which this kernel does not read again: the write-back at the kernel's end
+// (MI355X_MICROARCH.md "boundary": + dirty bytes / 6 TB/s) has nothing left to do.
+__device__ inline void store_through16(void *p, float4 v) {
+#ifdef CAFE_PLAIN_STORES
+    *reinterpret_cast<float4 *>(p) = v;
+#else
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(x) : "memory");
+#endif
+}
+
 }  // namespace cafe
+
+// Diagnostic build (make EXTRA=-DCAFE_PROF): thread 0 of every workgroup of a numbered kernel stamps the 100 MHz wall
+// clock when it enters and when it leaves; tools/step_windows.py turns the stamps into the timeline of one step as the
+// device ran it, without a profiler attached.  No code in the normal build.
+#ifdef CAFE_PROF
+constexpr int kWinKernels = 8, kWinBlocks = 4096;
+#define CAFE_KWIN_DECL(reader)                                                                                  \
+    __device__ unsigned long long g_kwin[kWinKernels][kWinBlocks][2];                                           \
+    extern "C" int reader(unsigned long long *out) {                                                            \
+        return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kwin), sizeof(g_kwin)) != hipSuccess;                      \
+    }
+struct KWinScope {
+    unsigned long long *p;
+    __device__ KWinScope(unsigned long long (*w)[kWinBlocks][2], int id) {
+        p = threadIdx.x == 0 && threadIdx.y == 0 ? w[id][(blockIdx.x + blockIdx.y * gridDim.x) & (kWinBlocks - 1)] : nullptr;
+        if (p) p[0] = wall_clock64();
+    }
+    __device__ ~KWinScope() { if (p) p[1] = wall_clock64(); }
+};
+#define CAFE_KWIN(id) KWinScope kwin_scope_(g_kwin, id)
+#else
+#define CAFE_KWIN_DECL(reader)
+#define CAFE_KWIN(id) do { } while (0)
+#endif

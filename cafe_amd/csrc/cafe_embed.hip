@@ -10,6 +10,8 @@
 
 #include "cafe_internal.h"
 
+CAFE_KWIN_DECL(cafe_debug_windows_embed)
+
 using namespace cafe;
 
 static inline double now_us() {
@@ -128,6 +130,7 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
                                                  float *__restrict__ out, const float *__restrict__ w_med = nullptr,
                                                  int median_n = 1, const DevState *__restrict__ st = nullptr, int gflip = 0,
                                                  int32_t *__restrict__ qmed = nullptr) {
+    CAFE_KWIN(0);
     // A wave takes 64 consecutive lookups.  First every lane resolves one lookup on its own (id, one 32-B probe of
     // val|dic, routing, source row address): three dependent memory steps for 64 lookups instead of per lookup.  Then
     // the wave copies the 64 rows, 64/LPG rows per instruction (LPG lanes x float4 = one row), eight instructions in
@@ -187,7 +190,7 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int r = j + u * RPI + sub;
-                    if (r < nrow && c < dim4) obase[(size_t)r * dim4 + c] = t[u];
+                    if (r < nrow && c < dim4) cafe::store_through16(&obase[(size_t)r * dim4 + c], t[u]);
                 }
             }
         }
@@ -302,6 +305,7 @@ static void norm_geometry(int batch, int *nparts, int *rows) {
 template <int LPG>
 __global__ void __launch_bounds__(256) k_grad_norm(const float *__restrict__ g, int batch, int rows, int dim,
                                                    float *__restrict__ gn, float *__restrict__ psum) {
+    CAFE_KWIN(1);
     constexpr int G = 256 / LPG;                 // row groups of the workgroup
     __shared__ float gs[G];
     const int part = blockIdx.x, f = blockIdx.y, nparts = gridDim.x;
@@ -514,6 +518,7 @@ __global__ void __launch_bounds__(256) k_migrate_list(const MainBucket *__restri
                                                       const int64_t *__restrict__ local_ids, const int32_t *__restrict__ gids,
                                                       const int32_t *__restrict__ ins, int batch, int total, int dim,
                                                       const uint32_t *__restrict__ gotcount, const uint32_t *__restrict__ gotlist) {
+    CAFE_KWIN(2);
     const uint32_t count = *gotcount;
     const int groups = (gridDim.x * blockDim.x) / LPG, gi = (blockIdx.x * blockDim.x + threadIdx.x) / LPG, lig = threadIdx.x % LPG;
     const bool scan = count == 0xffffffffu;
@@ -592,6 +597,7 @@ __global__ void __launch_bounds__(1024) k_bwd_assign(int Ph, int Pc, const int32
                                                      const int32_t *__restrict__ hash_size, const int64_t *__restrict__ cold_base,
                                                      int hotn, int batch, int total, uint32_t *__restrict__ cnt,
                                                      uint32_t *__restrict__ rank, uint32_t *__restrict__ keys) {
+    CAFE_KWIN(3);
     extern __shared__ uint32_t hist[];
     const int P = Ph + Pc;
     for (int b = threadIdx.x; b < P; b += blockDim.x) hist[b] = 0;
@@ -614,6 +620,7 @@ __global__ void __launch_bounds__(1024) k_bwd_assign(int Ph, int Pc, const int32
 // offsets of the partitions, and the list of (partition, tile) work items: one workgroup per <= kBwdCap pairs
 __global__ void __launch_bounds__(1024) k_bwd_offsets(int Ph, int P, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off,
                                                       uint32_t *__restrict__ tiles /* [0] = hot tiles, [1] = all tiles, then (p << 8 | t)... */) {
+    CAFE_KWIN(4);
     __shared__ uint32_t sh[1024], sh2[1024];
     __shared__ uint32_t carry, carry2;
     if (threadIdx.x == 0) { carry = 0; carry2 = 0; }
@@ -646,6 +653,7 @@ __global__ void __launch_bounds__(1024) k_bwd_offsets(int Ph, int P, const uint3
 
 __global__ void k_bwd_scatter(int Ph, int Pc, int hotn, int total, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ rank,
                               const uint32_t *__restrict__ off, uint32_t *__restrict__ cnt, unsigned long long *__restrict__ items) {
+    CAFE_KWIN(5);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < Ph + Pc) cnt[i] = 0;                 // ready for the next call (k_bwd_offsets has consumed it)
     if (i >= total) return;
@@ -698,6 +706,7 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                                                       float *__restrict__ w_hot, float *const *__restrict__ w_cold,
                                                       const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr,
                                                       const int32_t *__restrict__ skip_if_2) {
+    CAFE_KWIN(6);
     __shared__ __attribute__((aligned(16))) unsigned long long key[kBwdCap];
     __shared__ float4 bpart[2][VPL][256];      // border partial sums: [0] head of a group's range, [1] tail
     __shared__ int bflag[256];
@@ -814,7 +823,7 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                                 } else {
                                     float4 w = wr[e][v];
                                     w.x -= lr * acc[v].x; w.y -= lr * acc[v].y; w.z -= lr * acc[v].z; w.w -= lr * acc[v].w;
-                                    reinterpret_cast<float4 *>(rowp[e])[c] = w;
+                                    cafe::store_through16(&reinterpret_cast<float4 *>(rowp[e])[c], w);
                                 }
                             }
                         }
@@ -852,7 +861,7 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                     } else {
                         float4 w = reinterpret_cast<const float4 *>(lead_row)[c];
                         w.x -= lr * sum[v].x; w.y -= lr * sum[v].y; w.z -= lr * sum[v].z; w.w -= lr * sum[v].w;
-                        reinterpret_cast<float4 *>(lead_row)[c] = w;
+                        cafe::store_through16(&reinterpret_cast<float4 *>(lead_row)[c], w);
                     }
                 }
             }
@@ -893,7 +902,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         hipLaunchKernelGGL(k_bwd_scatter, dim3((std::max(total, P) + 255) / 256), dim3(256), 0, pst, Ph, Pc, t->hotn, total, keys, rank, off,
                            cnt, items);
         if (pst != st) {
-            if (!t->ev_plan) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_plan, hipEventDisableTiming));
+            if (!t->ev_plan) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_plan, kDeviceEvent));
             CAFE_HIP_CHECK(hipEventRecord(t->ev_plan, pst));
         }
     }

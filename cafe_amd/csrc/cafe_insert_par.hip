@@ -32,6 +32,7 @@
 //
 // Nothing is written to the tables before the decision in k_commit.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstring>
 
 #include <algorithm>
@@ -40,9 +41,11 @@
 
 namespace cafe {
 
+CAFE_KWIN_DECL(cafe_debug_windows_insert)
+
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kChunk = 2048;          // ids per plan workgroup
+constexpr int kChunk = 1024;          // ids per plan workgroup
 constexpr int kPlanThreads = 512;     // 8 waves, 256 consecutive ids each
 constexpr int kPlanWaves = kPlanThreads / 64;
 constexpr int kPlanRows = kChunk / kPlanThreads;     // rows of 64 ids a plan wave walks
@@ -198,11 +201,14 @@ __device__ inline unsigned long long lanes_below() { return (1ull << (threadIdx.
 __global__ void __launch_bounds__(kPlanThreads) k_assign(Geo g, const MainBucket *__restrict__ mt, IdSrc ids,
                                                          uint16_t *__restrict__ cm /* [nchunks][nbins] */,
                                                          uint32_t *__restrict__ planA, uint32_t *__restrict__ planB) {
+    CAFE_KWIN(0);
     extern __shared__ uint16_t wh[];            // [kPlanWaves][nbins]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = g.nbins;
+    CAFE_STAMP(4, 0);
     for (int b = tid; b < (kPlanWaves * nb + 1) / 2; b += kPlanThreads) reinterpret_cast<uint32_t *>(wh)[b] = 0;
     __syncthreads();
+    CAFE_STAMP(4, 1);
     uint16_t *mine = wh + (size_t)wave * nb;
     const int bitsb = 32 - __builtin_clz((unsigned)(nb | 1));
     const unsigned long long below = lanes_below();
@@ -224,6 +230,8 @@ __global__ void __launch_bounds__(kPlanThreads) k_assign(Geo g, const MainBucket
         const int4 *p = reinterpret_cast<const int4 *>(&mt[b1s[r]]);
         vs[r] = p[0]; ds[r] = p[1]; fl[r] = mt[b1s[r]].flip;
     }
+    if (xs[0] == 0xdeadbeefu && vs[0].x == 0x1234567) CAFE_STAMP(4, 7);      // (diagnostic build: forces the loads to land before the stamp)
+    CAFE_STAMP(4, 2);
 #pragma unroll
     for (int r = 0; r < kPlanRows; ++r) {
         const int i = base + r * 64 + lane;
@@ -268,7 +276,9 @@ __global__ void __launch_bounds__(kPlanThreads) k_assign(Geo g, const MainBucket
             wb[r] = has_b ? ((old + (uint32_t)__popcll(m & below)) | (binB << 11)) : 0xffffffffu;
         }
     }
+    CAFE_STAMP(4, 3);
     __syncthreads();
+    CAFE_STAMP(4, 4);
     // per bin: exclusive prefix over the waves (batch order), chunk total to the column matrix
     for (int b = tid; b < nb; b += kPlanThreads) {
         uint32_t run = 0;
@@ -281,6 +291,7 @@ __global__ void __launch_bounds__(kPlanThreads) k_assign(Geo g, const MainBucket
         cm[(size_t)blockIdx.x * nb + b] = (uint16_t)run;
     }
     __syncthreads();
+    CAFE_STAMP(4, 5);
 #pragma unroll
     for (int r = 0; r < kPlanRows; ++r) {
         const int i = base + r * 64 + lane;
@@ -288,6 +299,7 @@ __global__ void __launch_bounds__(kPlanThreads) k_assign(Geo g, const MainBucket
         planA[i] = wa[r] + mine[(wa[r] >> 11) & 0x1fffu];
         if (wb[r] != 0xffffffffu) planB[i] = wb[r] + mine[(wb[r] >> 11) & 0x1fffu];
     }
+    CAFE_STAMP(4, 6);
 }
 
 // Column prefix sums over the chunks: a workgroup takes 32 bins, eight lanes share a bin's column.  The workgroup that
@@ -297,8 +309,10 @@ constexpr int kOffBins = 32, kOffParts = kThreads / kOffBins;
 __global__ void __launch_bounds__(kThreads) k_offsets(Geo g, const uint16_t *__restrict__ cm, uint32_t *__restrict__ colpref,
                                                       uint32_t *__restrict__ tot, uint32_t *__restrict__ off, Ctl *ctl,
                                                       uint32_t *__restrict__ evcnt, DevState *st) {
+    CAFE_KWIN(1);
     __shared__ uint32_t sh[kThreads];
-    __shared__ uint32_t carry, last;
+    __shared__ uint32_t excl[kMaxPlanBins + 1];
+    __shared__ uint32_t last;
     const int tid = threadIdx.x;
     CAFE_STAMP(3, 0);
     {
@@ -307,32 +321,54 @@ __global__ void __launch_bounds__(kThreads) k_offsets(Geo g, const uint16_t *__r
         const int c0 = part * cpp, c1 = min(c0 + cpp, g.nchunks);
         const bool live = b < g.nbins;
         const int bb = live ? b : 0;
-        uint32_t sum = 0;
-        for (int c = c0; c < c1; c += 8) {          // eight independent loads per step
-            uint32_t v[8];
+        if (cpp <= 32) {
+            // the column piece stays in registers: one memory round trip
+            uint32_t v[32], sum = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = cm[(size_t)min(c + u, g.nchunks - 1) * g.nbins + bb];
+            for (int u = 0; u < 32; ++u) v[u] = cm[(size_t)min(c0 + u, g.nchunks - 1) * g.nbins + bb];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) sum += (c + u < c1) ? v[u] : 0u;
+            for (int u = 0; u < 32; ++u) { v[u] = (c0 + u < c1) ? v[u] : 0u; sum += v[u]; }
+            sh[tid] = live ? sum : 0u;
+            __syncthreads();
+            CAFE_STAMP(3, 1);
+            uint32_t run = 0, total = 0;
+            for (int k = 0; k < kOffParts; ++k) {
+                const uint32_t x = sh[k * kOffBins + (tid & (kOffBins - 1))];
+                if (k < part) run += x;
+                total += x;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if (live && c0 + u < c1) { colpref[(size_t)(c0 + u) * g.nbins + b] = run; run += v[u]; }
+            if (live && part == 0) __hip_atomic_store(&tot[b], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            uint32_t sum = 0;
+            for (int c = c0; c < c1; c += 8) {          // eight independent loads per step
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = cm[(size_t)min(c + u, g.nchunks - 1) * g.nbins + bb];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += (c + u < c1) ? v[u] : 0u;
+            }
+            sh[tid] = live ? sum : 0u;
+            __syncthreads();
+            CAFE_STAMP(3, 1);
+            uint32_t run = 0, total = 0;
+            for (int k = 0; k < kOffParts; ++k) {
+                const uint32_t x = sh[k * kOffBins + (tid & (kOffBins - 1))];
+                if (k < part) run += x;
+                total += x;
+            }
+            for (int c = c0; c < c1; c += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = cm[(size_t)min(c + u, g.nchunks - 1) * g.nbins + bb];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (live && c + u < c1) { colpref[(size_t)(c + u) * g.nbins + b] = run; run += v[u]; }
+            }
+            if (live && part == 0) __hip_atomic_store(&tot[b], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        sh[tid] = live ? sum : 0u;
-        __syncthreads();
-        CAFE_STAMP(3, 1);
-        uint32_t run = 0, total = 0;
-        for (int k = 0; k < kOffParts; ++k) {
-            const uint32_t v = sh[k * kOffBins + (tid & (kOffBins - 1))];
-            if (k < part) run += v;
-            total += v;
-        }
-        for (int c = c0; c < c1; c += 8) {
-            uint32_t v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = cm[(size_t)min(c + u, g.nchunks - 1) * g.nbins + bb];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (live && c + u < c1) { colpref[(size_t)(c + u) * g.nbins + b] = run; run += v[u]; }
-        }
-        if (live && part == 0) __hip_atomic_store(&tot[b], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -349,49 +385,55 @@ __global__ void __launch_bounds__(kThreads) k_offsets(Geo g, const uint16_t *__r
     __syncthreads();
     CAFE_STAMP(3, 2);
     if (!last) return;
-    // three exclusive scans: main bins (C and M of a partition adjacent), LRU bins, hot bins.  A lane takes 16 consecutive
-    // bins; lane totals are scanned by shuffles, wave totals through LDS.
-    uint32_t over = 0, maxpart = 0, maxhot = 0, nclassc = 0;
-    for (int list = 0; list < 3; ++list) {
-        const int b0 = list == 0 ? 0 : list == 1 ? bin_lru0(g) : bin_hot0(g);
-        const int cnt = list == 0 ? 2 * g.P1 : list == 1 ? g.P2 : g.PH;
-        uint32_t *o = off + (list == 0 ? 0 : list == 1 ? off_lru0(g) : off_hot0(g));
-        if (tid == 0) carry = 0;
-        __syncthreads();
-        for (int base = 0; base < cnt; base += 16 * kThreads) {
-            uint32_t v[16], sum = 0;
+    // One exclusive scan over all bins (main bins with C and M of a partition adjacent, LRU bins, hot bins), kept in LDS;
+    // each list's offsets are the scan less the value at the list's first bin.  A lane takes `per` consecutive bins.
+    {
+        const int per = (g.nbins + kThreads - 1) / kThreads;          // <= 32 (kMaxPlanBins / kThreads)
+        uint32_t v[32], sum = 0;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int i = base + tid * 16 + u;
-                v[u] = i < cnt ? __hip_atomic_load(&tot[b0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                sum += v[u];
-                if (list == 0) { if (u & 1) { maxpart = max(maxpart, v[u] + v[u - 1]); nclassc += v[u - 1]; } }
-                else if (list == 1) maxpart = max(maxpart, v[u]);
-                else maxhot = max(maxhot, v[u]);
-            }
-            uint32_t inc = sum;
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((tid & 63) >= d) inc += x; }
-            if ((tid & 63) == 63) sh[tid >> 6] = inc;
-            __syncthreads();
-            uint32_t run = carry + inc - sum;
-            for (int w = 0; w < (tid >> 6); ++w) run += sh[w];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int i = base + tid * 16 + u;
-                if (i < cnt) o[i] = run;
-                run += v[u];
-            }
-            __syncthreads();
-            if (tid == kThreads - 1) carry = run;
-            __syncthreads();
+        for (int u = 0; u < 32; ++u) {
+            const int i = tid * per + u;
+            v[u] = (u < per && i < g.nbins) ? __hip_atomic_load(&tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            sum += v[u];
         }
-        if (tid == 0) o[cnt] = carry;
+        uint32_t inc = sum;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((tid & 63) >= d) inc += x; }
+        if ((tid & 63) == 63) sh[tid >> 6] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (int w = 0; w < (tid >> 6); ++w) run += sh[w];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int i = tid * per + u;
+            if (u < per && i < g.nbins) excl[i] = run;
+            run += v[u];
+        }
+        if (tid == kThreads - 1) excl[g.nbins] = run;
         __syncthreads();
     }
-    (void)over;
+    uint32_t maxpart = 0, maxhot = 0, nclassc = 0;
+    {
+        const int l1 = bin_lru0(g), l2 = bin_hot0(g);
+        const uint32_t base1 = excl[l1], base2 = excl[l2], total = excl[g.nbins];
+        for (int i = tid; i < g.nbins; i += kThreads) {
+            const uint32_t e = excl[i], c = excl[i + 1] - e;
+            if (i < l1) {
+                off[i] = e;
+                if (!(i & 1)) { nclassc += c; maxpart = max(maxpart, excl[i + 2] - e); }
+            } else if (i < l2) {
+                off[off_lru0(g) + (i - l1)] = e - base1;
+                maxpart = max(maxpart, c);
+            } else {
+                off[off_hot0(g) + (i - l2)] = e - base2;
+                maxhot = max(maxhot, c);
+            }
+        }
+        if (tid == 0) {
+            off[l1] = base1;                                  // list totals close each list
+            off[off_lru0(g) + g.P2] = base2 - base1;
+            off[off_hot0(g) + g.PH] = total - base2;
+        }
+    }
     CAFE_STAMP(3, 3);
     // control block and move counters start at zero; the LRU clock placeholder clock0 + 1 + position must stay positive
     uint32_t *cw = reinterpret_cast<uint32_t *>(ctl);
@@ -418,10 +460,16 @@ __global__ void __launch_bounds__(kThreads) k_offsets(Geo g, const uint16_t *__r
     CAFE_STAMP(3, 4);
 }
 
+// a record leaves as one written-through 16-byte store (nothing for the kernel's end to write back)
+__device__ inline void put_rec(Rec *p, const Rec &r) {
+    store_through16(p, make_float4(__uint_as_float(r.pos), __uint_as_float(r.x), __uint_as_float(r.bl), __uint_as_float(r.pad)));
+}
+
 __global__ void __launch_bounds__(256) k_scatter(Geo g, IdSrc ids, const uint32_t *__restrict__ planA,
                                                  const uint32_t *__restrict__ planB, const uint32_t *__restrict__ colpref,
                                                  const uint32_t *__restrict__ off, Rec *__restrict__ rec1, Rec *__restrict__ rec2,
                                                  Rec *__restrict__ rech, uint8_t *__restrict__ miss) {
+    CAFE_KWIN(2);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= g.n) return;
     const uint32_t x = ids.at(i);
@@ -435,19 +483,19 @@ __global__ void __launch_bounds__(256) k_scatter(Geo g, IdSrc ids, const uint32_
     if (binA >= bin_hot0(g)) {
         const int ph = binA - bin_hot0(g);
         r.bl = ((uint32_t)(h1 - ph * g.bpph) << 2) | ((a >> 24) & 3u);
-        rech[off[off_hot0(g) + ph] + rankA] = r;
+        put_rec(&rech[off[off_hot0(g) + ph] + rankA], r);
         miss[i] = 0;
         return;
     }
     const uint32_t mbit = (a >> 26) & 1u ? kMissBit : 0u;
     const int p1 = binA >> 1;
     r.bl = (uint32_t)(h1 - p1 * g.bpp1) | mbit;
-    rec1[off[binA] + rankA] = r;
+    put_rec(&rec1[off[binA] + rankA], r);
     const uint32_t b = planB[i];
     const int binB = (int)((b >> 11) & 0x1fffu);
     const int p2 = binB - bin_lru0(g);
     r.bl = (uint32_t)(fast_hash(x, g.fm2) - p2 * g.bpp2) | mbit;
-    rec2[off[off_lru0(g) + p2] + (b & 0x7ffu) + colpref[(size_t)chunk * g.nbins + binB]] = r;
+    put_rec(&rec2[off[off_lru0(g) + p2] + (b & 0x7ffu) + colpref[(size_t)chunk * g.nbins + binB]], r);
     miss[i] = mbit ? 1 : 0;
 }
 
@@ -1371,6 +1419,7 @@ struct HotArgs {
 
 template <int CAP>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CAP <= 1024 ? 8 : 1, 8))) k_round1(Geo g, MainArgs MA, LruArgs LA, HotArgs HA, Score sc) {
+    CAFE_KWIN(3);
     __shared__ __attribute__((aligned(16))) OwnerLds<CAP, false> L;
     __shared__ int heavy[kMaxHeavy];
     __shared__ int n_heavy, s_total;
@@ -1447,6 +1496,7 @@ __device__ inline bool grid_barrier(Ctl *ctl, uint32_t &gen) {
 
 template <int CAP>
 __global__ void __launch_bounds__(kThreads) k_fix(Geo g, MainArgs MA, LruArgs LA, Score sc) {
+    CAFE_KWIN(4);
     g.prof = 5;
     __shared__ __attribute__((aligned(16))) OwnerLds<CAP, true> L;
     __shared__ int heavy[kMaxHeavy];
@@ -1500,6 +1550,7 @@ __global__ void __launch_bounds__(kScanBlock) k_finish(
     int32_t *__restrict__ pushval, unsigned long long *agg /* [nblocks][2] */, uint32_t *__restrict__ poprank,
     uint32_t *__restrict__ pushrank, uint32_t *__restrict__ clkrank, uint32_t *__restrict__ gotlist, Score sc,
     float *__restrict__ scores_out) {
+    CAFE_KWIN(5);
     __shared__ uint32_t wsum[3][kScanBlock / 64];
     __shared__ uint32_t s_cross;
     __shared__ uint32_t s_base[4];
@@ -1634,6 +1685,7 @@ struct CommitArgs {
 // finishes last applies the batch totals to the device scalars and leaves the snapshot for the host -- or, for a batch
 // that was not settled and is not to be handed back to the host, walks it in order from the untouched tables.
 __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
+    CAFE_KWIN(6);
     __shared__ int s_verdict, s_reason, s_last;
     __shared__ float fsum[kMaxSeg];
     const int tid = threadIdx.x;
@@ -1912,7 +1964,8 @@ static int pick_cap(cafe_sketch *s, int n) {
 
 // The plan of an insert of n ids: classification, partition offsets, item records; per-call scalars and a zeroed
 // control block.  Reads the ids and the pre-batch tables only.
-static int launch_plan(cafe_sketch *s, Geo &g, const IdSrc &ids, hipStream_t pre) {
+// `done`: an event completed by the last plan kernel itself (its completion signal; no marker packet behind it)
+static int launch_plan(cafe_sketch *s, Geo &g, const IdSrc &ids, hipStream_t pre, hipEvent_t done = nullptr) {
     ParWorkspace &w = *s->par;
     const int n = g.n;
     Ctl *ctl = w.ctl.as<Ctl>();
@@ -1929,8 +1982,9 @@ static int launch_plan(cafe_sketch *s, Geo &g, const IdSrc &ids, hipStream_t pre
     hipLaunchKernelGGL(k_assign, dim3(g.nchunks), dim3(kPlanThreads), plan_lds, pre, g, s->d_main, ids, w.cm.as<uint16_t>(), planA, planB);
     hipLaunchKernelGGL(k_offsets, dim3((g.nbins + kOffBins - 1) / kOffBins), dim3(kThreads), 0, pre, g, w.cm.as<uint16_t>(),
                        w.colpref.as<uint32_t>(), w.tot.as<uint32_t>(), off, ctl, evcnt, s->d_state);
-    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, pre, g, ids, planA, planB, w.colpref.as<uint32_t>(), off, rec1, rec2,
-                       rech, w.miss.as<uint8_t>());
+    hipExtLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, pre, nullptr, done, 0, g, ids, (const uint32_t *)planA,
+                          (const uint32_t *)planB, (const uint32_t *)w.colpref.as<uint32_t>(), (const uint32_t *)off, rec1, rec2, rech,
+                          w.miss.as<uint8_t>());
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1943,8 +1997,7 @@ int par_plan_ahead(cafe_sketch *s, const int64_t *d_local_ids, const int64_t *d_
     g.flip_now = 0;
     IdSrc ids;
     ids.gids = nullptr; ids.local_ids = d_local_ids; ids.id_offset = d_id_offset; ids.batch = batch;
-    if (launch_plan(s, g, ids, side)) return 1;
-    CAFE_HIP_CHECK(hipEventRecord(s->ev_plan, side));
+    if (launch_plan(s, g, ids, side, s->ev_plan)) return 1;
     s->plan_valid = 1; s->plan_seq = s->call_seq; s->plan_n = n; s->plan_ids = d_local_ids; s->plan_flip = s->flip;
     s->plan_hot = s->opt_hot_bypass; s->plan_target = s->opt_target_items;
     return 0;

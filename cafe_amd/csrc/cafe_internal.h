@@ -35,6 +35,9 @@ struct ParWorkspace;   // parallel insert workspace, cafe_insert_par.hip
 
 }  // namespace cafe
 
+// events that order work of one device only: no timing, device-scope release (no system-scope cache write-back)
+constexpr unsigned kDeviceEvent = hipEventDisableTiming | hipEventReleaseToDevice;
+
 struct cafe_sketch {
     int device = 0;
     int lim = 0, n1 = 0, n2 = 0, adjust = 1, lru_first = 1;
@@ -74,8 +77,6 @@ struct cafe_sketch {
     int opt_plan_ahead = 1, unused_plans = 0;
     double host_us[4] = {0, 0, 0, 0};   // diagnostics (cafe_debug_host_times)
     long long counters_plan_ahead = 0;
-    hipEvent_t ev_done = nullptr;       // recorded behind the closing kernel of every insert
-    int ev_done_valid = 0;
     long long last_seen_batch = -1;
     // real_n as the host knows it without a sync: the last snapshot of the pinned mirror plus the ids of the calls
     // issued since (see real_n_bound in cafe_sketch.hip)

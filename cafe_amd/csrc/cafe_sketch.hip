@@ -3,6 +3,7 @@
 //
 // The parallel insert lives in cafe_insert_par.hip; this file holds everything else the sketch needs.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -346,12 +347,17 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     CAFE_HIP_CHECK(hipHostMalloc((void **)&s->h_pinned, 256, hipHostMallocMapped));
     memset(s->h_pinned, 0, 256);
     CAFE_HIP_CHECK(hipHostGetDevicePointer((void **)&s->d_pinned, s->h_pinned, 0));
-    CAFE_HIP_CHECK(hipStreamCreateWithFlags(&s->side_stream, hipStreamNonBlocking));
+    {
+        // the second stream carries the short plan kernels beside the bandwidth kernels: highest priority, so that
+        // their workgroups are placed as soon as compute-unit slots free up
+        int prio_least = 0, prio_most = 0;
+        CAFE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_most));
+        CAFE_HIP_CHECK(hipStreamCreateWithPriority(&s->side_stream, hipStreamNonBlocking, prio_most));
+    }
     if (const char *e = getenv("CAFE_OVERLAP")) s->opt_overlap = atoi(e);
-    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_fork, hipEventDisableTiming));
-    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_join, hipEventDisableTiming));
-    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
-    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_plan, hipEventDisableTiming));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_fork, kDeviceEvent));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_join, kDeviceEvent));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_plan, kDeviceEvent));
     if (s->ws_misc.reserve(4096)) return 1;
     CAFE_HIP_CHECK(hipMemset(s->d_main, 0, sizeof(MainBucket) * (size_t)s->n1));
     CAFE_HIP_CHECK(hipMemset(s->d_lru, 0, sizeof(LruBucket) * (size_t)s->n2));
@@ -372,7 +378,6 @@ extern "C" int cafe_sketch_destroy(cafe_sketch_t *s) {
     if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
     if (s->ev_head_fork) (void)hipEventDestroy(s->ev_head_fork);
     if (s->ev_head_join) (void)hipEventDestroy(s->ev_head_join);
-    if (s->ev_done) (void)hipEventDestroy(s->ev_done);
     if (s->ev_plan) (void)hipEventDestroy(s->ev_plan);
     s->ws_reset_keys.release(); s->ws_reset_keys2.release(); s->ws_reset_tmp.release();
     s->ws_reset_flags.release(); s->ws_misc.release();
@@ -684,10 +689,19 @@ bool cafe::threshold_known_above_one(cafe_sketch *s) {
     return s->thr_dirty_seq == 0 && s->host_thr > 1.0f;
 }
 
-// waits for the insert issued last; afterwards the snapshot in pinned memory is that call's
+// waits for the insert issued last; afterwards the snapshot in pinned memory is that call's.  The closing kernel writes
+// the snapshot, a system-scope fence, then its call number: the host polls that word (no event in the stream, no
+// interrupt), and falls back to a stream synchronisation when the call takes long (the in-order paths).
 static int wait_last(cafe_sketch *s, Mirror *m) {
-    if (s->ev_done_valid) CAFE_HIP_CHECK(hipEventSynchronize(s->ev_done));
-    else CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));
+    const volatile uint32_t *seqp = &reinterpret_cast<const volatile Mirror *>(s->h_pinned)->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (long spin = 0; !seen; ++spin) {
+        if (*seqp == s->call_seq) { seen = true; break; }
+        __builtin_ia32_pause();
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    if (!seen) CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));
     read_mirror(s, m);
     if (m->seq != s->call_seq) { set_error("internal: state snapshot %u does not belong to call %u", m->seq, s->call_seq); return 1; }
     take_snapshot(s, *m);
@@ -775,8 +789,6 @@ int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_val
     }
     if (rc == 0) {
         s->last_stream = st;       // the closing kernel mirrors the device state into pinned host memory
-        CAFE_HIP_CHECK(hipEventRecord(s->ev_done, st));
-        s->ev_done_valid = 1;
     }
     return rc;
 }

@@ -56,3 +56,4 @@ show("finish", buf[1], [(1, "scores out"), (2, "flags"), (3, "look-back"), (4, "
 show("commit", buf[2], [(1, "verdict"), (2, "partitions"), (3, "ticket"), (4, "close (last)")])
 show("offsets", buf[3], [(1, "column sums"), (2, "prefix+ticket"), (3, "bin scans (last)"), (4, "zero+scalars (last)")])
 print(eng.sketch.counters())
+show("assign", buf[4], [(1, "zero LDS"), (2, "ids+probes landed"), (3, "classify+rank (wave 0)"), (4, "all waves"), (5, "wave prefix+column"), (6, "plan words out")])
