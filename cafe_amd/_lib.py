@@ -41,6 +41,7 @@ SYMBOLS = {
     "cafe_sketch_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
     "cafe_sketch_counters": (ctypes.c_int, [_vp, _i64p]),
     "cafe_sketch_fallback_reasons": (ctypes.c_int, [_vp, _vp]),
+    "cafe_sketch_clock_renorms": (ctypes.c_int, [_vp, _vp]),
     "cafe_query_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "cafe_query_median_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "cafe_insert_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp]),

@@ -119,6 +119,28 @@ __global__ void k_count(const MainBucket *__restrict__ mt, int n1, const int32_t
 // applies it in its own k_offsets): the flip decision is made on the host (it depends on the call count
 // only); the threshold lives on the device because reset() rewrites it there.
 // ------------------------------------------------------------------------------------------------
+// The LRU clock (sketch.cpp:17 `t`) only ever grows, one tick per main-table miss, and the reference's victim search
+// starts from the constant 1e9 (sketch.cpp:159): past 1e9 ticks it stops finding victims, past 2^31 the clock wraps.
+// Only the order of the four timestamps inside a bucket matters, so long before that the host has every bucket's
+// timestamps rewritten to their ranks 1..4 (0 = never used stays 0) and the clock set to 4.  A deviation from the
+// reference's absolute timestamp values where the reference itself is about to become undefined; every decision
+// (victims, ins[], que[]) is unchanged.
+constexpr int32_t kClockRenormAt = 1 << 29;
+__global__ void k_clock_renorm(LruBucket *lt, int n2, DevState *st) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n2) {
+        int32_t t[kSlots], r[kSlots];
+        for (int i = 0; i < kSlots; ++i) t[i] = lt[k].t[i];
+        for (int i = 0; i < kSlots; ++i) {
+            int below = 0;
+            for (int j = 0; j < kSlots; ++j) below += (t[j] != 0 && t[j] < t[i]) ? 1 : 0;
+            r[i] = t[i] != 0 ? below + 1 : 0;
+        }
+        for (int i = 0; i < kSlots; ++i) lt[k].t[i] = r[i];
+    }
+    if (k == 0) st->clk = kSlots;
+}
+
 __global__ void k_prologue(DevState *st, int flip_now, int gflip) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (flip_now) st->thr = (float)((double)st->thr / kDecayV);
@@ -429,6 +451,11 @@ static int read_state(cafe_sketch *s, DevState *h) {
     return 0;
 }
 
+extern "C" int cafe_sketch_clock_renorms(cafe_sketch_t *s, int64_t *out) {
+    *out = s->clock_renorms;
+    return 0;
+}
+
 extern "C" int cafe_sketch_dims(cafe_sketch_t *s, int32_t *out) {
     DevState h;
     if (read_state(s, &h)) return 1;
@@ -479,6 +506,17 @@ extern "C" int cafe_sketch_import(cafe_sketch_t *s, const int32_t *mval, const f
                                   const int32_t *lt, const uint8_t *lflip, const uint32_t *fifo, int fifo_len,
                                   float thr, const int32_t *ints6, double decay) {
     if (fifo_len < 0 || (uint32_t)fifo_len > s->fifo_cap) { set_error("import: bad free-list length %d", fifo_len); return 1; }
+    // hot-table slots index rows of the caller's hot table (W_h[slot]); a value outside [0, lim) would address memory
+    // the reference merely aliases (|dic| % hot_nums, sk_embedding_bag.py:134)
+    for (size_t i = 0; i < (size_t)s->n1 * kSlots; ++i)
+        if (mdic[i] < 0 || mdic[i] >= s->lim) { set_error("import: main-table slot %d outside [0, %d)", mdic[i], s->lim); return 1; }
+    for (size_t i = 0; i < (size_t)s->n2 * kSlots; ++i) {
+        if (ldic[i] < 0 || ldic[i] >= s->lim) { set_error("import: LRU-table slot %d outside [0, %d)", ldic[i], s->lim); return 1; }
+        if (lt[i] < 0 || lt[i] > ints6[2]) { set_error("import: LRU timestamp %d outside [0, clock %d]", lt[i], ints6[2]); return 1; }
+    }
+    for (int i = 0; i < fifo_len; ++i)
+        if (fifo[i] == 0 || fifo[i] >= (uint32_t)s->lim) { set_error("import: free slot %u outside [1, %d)", fifo[i], s->lim); return 1; }
+    if (ints6[2] < 0) { set_error("import: negative LRU clock %d", ints6[2]); return 1; }
     std::vector<MainBucket> hm((size_t)s->n1);
     std::vector<LruBucket> hl((size_t)s->n2);
     std::vector<uint32_t> hf((size_t)s->fifo_cap, 0u);
@@ -510,6 +548,7 @@ extern "C" int cafe_sketch_import(cafe_sketch_t *s, const int32_t *mval, const f
     s->flip = ints6[3]; s->batch_num = ints6[4]; s->decay = decay;
     s->plan_valid = 0;
     s->base_real_n = h.real_n;
+    s->base_clk = h.clk;
     s->base_seq = s->call_seq;
     s->host_thr = thr;
     s->thr_dirty_seq = 0;
@@ -664,6 +703,7 @@ static void read_mirror(cafe_sketch *s, Mirror *out) {
 
 static void take_snapshot(cafe_sketch *s, const Mirror &m) {
     s->base_real_n = m.st.real_n;
+    s->base_clk = m.st.clk;
     s->base_seq = m.seq;
     s->fifo_hint = m.st.fifo_len;
     if (s->thr_dirty_seq && (int32_t)(m.seq - s->thr_dirty_seq) >= 0) {
@@ -678,6 +718,15 @@ long long cafe::real_n_bound(cafe_sketch *s) {
     if (m.seq != 0 && (int32_t)(m.seq - s->base_seq) > 0 && (int32_t)(s->call_seq - m.seq) >= 0) take_snapshot(s, m);
     if (s->call_seq - s->base_seq > 64u) return (long long)1 << 60;        // issued calls no longer in the ring
     long long ub = s->base_real_n;
+    for (uint32_t q = s->base_seq + 1; (int32_t)(s->call_seq - q) >= 0; ++q) ub += s->issued[q & 63].n;
+    return ub;
+}
+
+// the same for the LRU clock (at most one tick per id)
+static long long clk_bound(cafe_sketch *s) {
+    (void)cafe::real_n_bound(s);        // consumes the newest snapshot
+    if (s->call_seq - s->base_seq > 64u) return (long long)1 << 60;
+    long long ub = s->base_clk;
     for (uint32_t q = s->base_seq + 1; (int32_t)(s->call_seq - q) >= 0; ++q) ub += s->issued[q & 63].n;
     return ub;
 }
@@ -751,6 +800,16 @@ int cafe::insert_dev_on(cafe_sketch *s, const int32_t *d_ids, const float *d_val
         CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, pre));
         CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));
         pre = st;
+    }
+    // LRU clock lifetime (k_clock_renorm): every id ticks the clock at most once
+    if (clk_bound(s) + n + 2 >= (long long)kClockRenormAt) {
+        Mirror m;
+        if (s->call_seq != s->base_seq && wait_last(s, &m)) return 1;       // the exact clock
+        if ((long long)s->base_clk + n + 2 >= (long long)kClockRenormAt) {
+            hipLaunchKernelGGL(k_clock_renorm, dim3((s->n2 + 255) / 256), dim3(256), 0, pre, s->d_lru, s->n2, s->d_state);
+            s->base_clk = kSlots;
+            s->clock_renorms++;
+        }
     }
     // sketch.cpp:291
     if (s->adjust && (double)real_n_bound(s) > s->lim * 1.2) {

@@ -106,6 +106,9 @@ class HotSketch:
         why = (ctypes.c_int64 * 3)()
         self.L.cafe_sketch_fallback_reasons(self.h, why)
         d["left_parallel_path"] = {"workspace_limit": int(why[0]), "rounds_not_settled": int(why[1]), "free_list": int(why[2])}
+        ren = ctypes.c_int64()
+        self.L.cafe_sketch_clock_renorms(self.h, ctypes.byref(ren))
+        d["clock_renorms"] = int(ren.value)
         return d
 
     # -- the three reference operations ---------------------------------------------------------

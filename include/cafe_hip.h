@@ -108,6 +108,15 @@ int cafe_sketch_counters(cafe_sketch_t *s, int64_t *out8);
  * [0] a workspace limit (partition larger than an owner can sort, move list full, clock range), [1] the fix-point
  * rounds that were enqueued did not settle the batch, [2] the free list ran dry or was refilled inside the batch. */
 int cafe_sketch_fallback_reasons(cafe_sketch_t *s, int64_t *out3);
+/* Lifetime of the LRU clock (sketch.cpp:17 `t`, one tick per main-table miss): the reference's victim search starts
+ * from the constant 1e9 (sketch.cpp:159) and its int clock wraps at 2^31, so it is undefined from 1e9 ticks on (about
+ * 10^4 Criteo-Terabyte steps).  Only the order of the four timestamps inside an LRU bucket matters; when the clock
+ * would pass 2^29 within the next call, this library rewrites every bucket's timestamps to their ranks 1..4 (0 stays
+ * 0) and sets the clock to 4 before the call.  ins[], que[] and every other state word stay exactly the reference's;
+ * exported LRU timestamps differ from the reference's absolute values from that point on (same order).  *out = number
+ * of such rewrites since creation.  cafe_sketch_import rejects states whose slots, free-list entries or timestamps
+ * are out of range (slots index rows of the hot table). */
+int cafe_sketch_clock_renorms(cafe_sketch_t *s, int64_t *out);
 
 /* sketch.cpp:260-265 batch_query: d_que[i] = -slot if d_ids[i] holds a hot slot, else d_ids[i]. */
 int cafe_query_dev(cafe_sketch_t *s, const int32_t *d_ids, int n, int32_t *d_que, cafe_stream_t stream);

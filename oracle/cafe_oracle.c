@@ -310,3 +310,19 @@ void cafe_oracle_dump(const cafe_oracle_t *o, int32_t *mval, float *mcnt, int32_
     memcpy(lt, o->lt, b * 4); memcpy(lflip, o->lflip, o->n2);
     for (long i = 0; i < o->fifo_len; ++i) fifo[i] = o->fifo[(o->fifo_head + i) % o->fifo_cap];
 }
+
+/* Inverse of cafe_oracle_dump + cafe_oracle_scalars: lets a test continue from a prepared state (e.g. an LRU clock
+   close to the reference's 1e9 sentinel, sketch.cpp:159).  Test infrastructure; no counterpart in the reference. */
+void cafe_oracle_load(cafe_oracle_t *o, const int32_t *mval, const float *mcnt, const int32_t *mdic, const uint8_t *mflip,
+                      const int32_t *lval, const float *lcnt, const int32_t *ldic, const int32_t *lt, const uint8_t *lflip,
+                      const uint32_t *fifo, long fifo_len, float thr, const int32_t *ints /* 6 */, double decay) {
+    size_t a = (size_t)o->n1 * W, b = (size_t)o->n2 * W;
+    memcpy(o->mval, mval, a * 4); memcpy(o->mcnt, mcnt, a * 4); memcpy(o->mdic, mdic, a * 4);
+    memcpy(o->mflip, mflip, o->n1);
+    memcpy(o->lval, lval, b * 4); memcpy(o->lcnt, lcnt, b * 4); memcpy(o->ldic, ldic, b * 4);
+    memcpy(o->lt, lt, b * 4); memcpy(o->lflip, lflip, o->n2);
+    o->fifo_head = 0; o->fifo_len = fifo_len < o->fifo_cap ? fifo_len : o->fifo_cap;
+    for (long i = 0; i < o->fifo_len; ++i) o->fifo[i] = fifo[i];
+    o->thr = thr; o->num = ints[0]; o->real_n = ints[1]; o->clk = ints[2]; o->flip = ints[3];
+    o->batch_num = ints[4]; o->resets = ints[5]; o->decay = decay;
+}

@@ -51,6 +51,8 @@ def _lib():
         L.cafe_oracle_dims.argtypes = [ctypes.c_void_p, _i32p]
         L.cafe_oracle_scalars.argtypes = [ctypes.c_void_p, _f32p, _i32p, ctypes.POINTER(ctypes.c_double)]
         L.cafe_oracle_dump.argtypes = [ctypes.c_void_p, _i32p, _f32p, _i32p, _u8p, _i32p, _f32p, _i32p, _i32p, _u8p, _u32p]
+        L.cafe_oracle_load.argtypes = [ctypes.c_void_p, _i32p, _f32p, _i32p, _u8p, _i32p, _f32p, _i32p, _i32p, _u8p, _u32p,
+                                       ctypes.c_long, ctypes.c_float, _i32p, ctypes.c_double]
         _LIB = L
     return _LIB
 
@@ -111,6 +113,20 @@ class Oracle:
 
     def state(self):
         return read_state(self.L, "cafe_oracle_", self.h)
+
+    def load_state(self, st):
+        """Continue from a state dict as state() returns it (same lim): tests that start from a prepared state."""
+        a = {k: np.ascontiguousarray(st[k]) for k in ("mval", "mcnt", "mdic", "lval", "lcnt", "ldic", "lt")}
+        mflip = np.ascontiguousarray(st["mflip"], dtype=np.uint8)
+        lflip = np.ascontiguousarray(st["lflip"], dtype=np.uint8)
+        fifo = np.ascontiguousarray(st["fifo"], dtype=np.uint32)
+        ints = np.array([st["num"], st["real_n"], st["clk"], st["flip"], st["batch_num"], st.get("resets", 0)], np.int32)
+        self.L.cafe_oracle_load(
+            self.h, a["mval"].ctypes.data_as(_i32p), a["mcnt"].ctypes.data_as(_f32p), a["mdic"].ctypes.data_as(_i32p),
+            mflip.ctypes.data_as(_u8p), a["lval"].ctypes.data_as(_i32p), a["lcnt"].ctypes.data_as(_f32p),
+            a["ldic"].ctypes.data_as(_i32p), a["lt"].ctypes.data_as(_i32p), lflip.ctypes.data_as(_u8p),
+            fifo.ctypes.data_as(_u32p), len(fifo), ctypes.c_float(float(st["thr"])), ints.ctypes.data_as(_i32p),
+            float(st["decay"]))
 
     def stats(self):
         """Coverage counters: main hits, LRU hits, LRU misses, evictions moved to main, promotions,

@@ -198,3 +198,68 @@ def test_batches_that_leave_the_parallel_path_stay_exact(option, value, reason, 
     if reason:
         assert c["inorder_calls"] > 0 and c["left_parallel_path"][reason] > 0, c
         assert c["inorder_calls"] == sum(c["left_parallel_path"].values()), c
+
+
+def _ranks_in_buckets(lt):
+    """Per LRU bucket: 0 for a never-used slot, else 1 + number of smaller non-zero timestamps (k_clock_renorm)."""
+    t = np.asarray(lt, np.int64).reshape(-1, 4)
+    nz = t != 0
+    below = ((t[:, None, :] < t[:, :, None]) & nz[:, None, :]).sum(axis=2)
+    return np.where(nz, below + 1, 0).astype(np.int32).reshape(-1)
+
+
+@pytest.mark.parametrize("clock", [(1 << 29) - 3000, 1_000_000_000 - 2000, (1 << 31) - 9000],
+                         ids=["renorm_bound", "reference_sentinel_1e9", "int_wrap"])
+def test_lru_clock_lifetime(clock, oracle_mod):
+    """the LRU clock only grows (one tick per main-table miss).  The reference stops finding victims at 1e9
+    ticks (sketch.cpp:159) and wraps at 2^31.  The library rewrites the timestamps of every bucket to their ranks before
+    the clock passes 2^29 (cafe_hip.h, cafe_sketch_clock_renorms): decisions must stay those of a reference whose clock
+    is far from its sentinel.  Start both sides from the same warmed-up state, the library's copy with all timestamps
+    shifted up to `clock`, and compare ins[], que[] and the whole state (timestamps by their order inside the bucket)."""
+    from cafe_amd.sketch import HotSketch
+    lim, thr, batch, space = 3000, 3, 4096, 40000
+    ora = oracle_mod.Oracle(lim, thr, 1, 1.0000005, 1)
+    rng = np.random.default_rng(11)
+
+    def stream():
+        ids = ((rng.zipf(1.15, size=batch) - 1) % space + 1).astype(np.int64)
+        v = (rng.random(batch, dtype=np.float32) * np.float32(6.0)).astype(np.float32)
+        return ids, v
+
+    for _ in range(4):
+        ora.insert_val(*stream())
+    st = ora.state()
+    shifted = dict(st)
+    shift = clock - int(st["clk"])
+    shifted["lt"] = np.where(st["lt"] != 0, st["lt"].astype(np.int64) + shift, 0).astype(np.int32)
+    shifted["clk"] = clock
+    sk = HotSketch(lim, thr, 1, 1.0000005, 1)
+    sk.load_state_dict(shifted)
+    for c in range(6):
+        ids, v = stream()
+        want = ora.insert_val(ids, v)
+        got = sk.insert_val(ids, v).cpu().numpy()
+        assert np.array_equal(got, want), f"call {c}: ins differs"
+        assert np.array_equal(sk.query(ids).cpu().numpy(), ora.query(ids)), f"call {c}: que differs"
+    a, b = sk.state(), ora.state()
+    assert np.array_equal(_ranks_in_buckets(a["lt"]), _ranks_in_buckets(b["lt"]))
+    a["lt"] = b["lt"]; a["clk"] = b["clk"]
+    assert not oracle_mod.states_equal(a, b)
+    c = sk.counters()                       # also raises if the commit kernel refused a staged entry (bad_commit)
+    assert c["clock_renorms"] >= 1 and c["inorder_calls"] == 0 and c["cadence_miss"] == 0, c
+    assert 0 < sk.state()["clk"] < (1 << 29)
+
+
+def test_import_rejects_out_of_range_state():
+    from cafe_amd.sketch import HotSketch
+    sk = HotSketch(500, 2, 1, 1.0, 1)
+    sk.insert_val(np.arange(1, 2000, dtype=np.int64) % 700 + 1, np.full(1999, 3.0, np.float32))
+    good = sk.state()
+    for key, idx, val in (("mdic", 0, 500), ("ldic", 1, -3), ("fifo", 0, 0), ("fifo", 0, 500), ("lt", 2, -1)):
+        bad = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in good.items()}
+        if len(bad[key]) <= idx:
+            continue
+        bad[key][idx] = val
+        with pytest.raises(RuntimeError):
+            sk.load_state_dict(bad)
+    sk.load_state_dict(good)
