@@ -56,6 +56,11 @@ extern "C" int cafe_tables_create(cafe_tables_t **out, int num_fields, int dim, 
     std::vector<int64_t> base(num_fields + 1, 0);
     for (int f = 0; f < num_fields; ++f) {
         if (hash_size[f] <= 0) { set_error("cafe_tables_create: hash_size[%d] = %d", f, hash_size[f]); delete t; return 1; }
+        // global ids are the sketch's 32-bit keys and the sign of a routing word tells hot from cold (sk_embedding_bag.py:
+        // 121-123): a field whose ids start at 2^31 or beyond cannot be represented
+        if (id_offset[f] < 0 || id_offset[f] >= ((int64_t)1 << 31)) {
+            set_error("cafe_tables_create: id_offset[%d] = %lld outside [0, 2^31)", f, (long long)id_offset[f]); delete t; return 1;
+        }
         base[f + 1] = base[f] + hash_size[f];
     }
     t->total_cold_rows = base[num_fields];
@@ -106,6 +111,9 @@ extern "C" int cafe_tables_destroy(cafe_tables_t *t) {
     return 0;
 }
 
+// row of the hot table for a routing word q < 0: sk_embedding_bag.py:134 `abs(dic) % hot_nums`
+__device__ inline uint32_t hot_row(int32_t q, int hotn) { return (0u - (uint32_t)q) % (uint32_t)hotn; }
+
 static inline int lanes_per_row(int dim) {
     int v = dim / 4, l = 1;
     while (l < v) l <<= 1;
@@ -125,7 +133,7 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
                                                  const int64_t *__restrict__ id_offset, const int32_t *__restrict__ hash_size,
                                                  const int64_t *__restrict__ local_ids,
                                                  const int32_t *__restrict__ in_gids, const int32_t *__restrict__ fields,
-                                                 int batch, int total, int dim,
+                                                 int batch, int total, int dim, int hotn,
                                                  int32_t *__restrict__ gids, int32_t *__restrict__ que,
                                                  float *__restrict__ out, const float *__restrict__ w_med = nullptr,
                                                  int median_n = 1, const DevState *__restrict__ st = nullptr, int gflip = 0,
@@ -153,7 +161,9 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
             const int32_t val[4] = {v.x, v.y, v.z, v.w}, dic[4] = {d.x, d.y, d.z, d.w};
             const int32_t q = query_bucket(val, dic, x);
             // hot: W_h[|q| % hotn] = W_h[slot]; cold: W_hash[|q| % hash_size] (sk_embedding_bag.py:134-150)
-            row = q < 0 ? w_hot + (size_t)(-q) * dim : w_cold[f] + (size_t)((uint32_t)q % (uint32_t)hash_size[f]) * dim;
+            // (the modulo on the hot side is the reference's `abs(dic) % hot_nums`: a slot is < lim <= hotn, so it only
+            // matters for a negative global id, which the reference aliases onto a hot row as well)
+            row = q < 0 ? w_hot + (size_t)(hot_row(q, hotn)) * dim : w_cold[f] + (size_t)((uint32_t)q % (uint32_t)hash_size[f]) * dim;
             if (gids) gids[i] = g;
             que[i] = q;
             if constexpr (ML) {
@@ -197,11 +207,19 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
     }
 }
 
+// a slot handed out by the sketch (< lim) must be a row of the hot table: the reference aliases a larger slot onto
+// another row (`abs(dic) % hot_nums`, sk_embedding_bag.py:134); here that pairing is refused
+static int pair_ok(const cafe_sketch_t *s, const cafe_tables_t *t, const char *what) {
+    if (s->lim > t->hotn) { set_error("%s: the sketch hands out slots up to %d but the hot table has %d rows", what, s->lim - 1, t->hotn); return 1; }
+    return 0;
+}
+
 static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_in_gids,
                           const int32_t *d_fields, int batch, long total_l, int32_t *d_gids, int32_t *d_que, float *d_out,
                           hipStream_t st) {
     if (total_l == 0) return 0;
     if (batch <= 0 || total_l < 0 || total_l > 0x7fffffffL / 4) { set_error("cafe forward: bad size %ld", total_l); return 1; }
+    if (pair_ok(s, t, "cafe_forward_dev")) return 1;
     const double t_begin = now_us();
     const int total = (int)total_l;
     const int lpg = lanes_per_row(t->dim);
@@ -225,7 +243,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     }
 #define CAFE_FWD(L)                                                                                              \
     hipLaunchKernelGGL((k_forward<L, false>), dim3(blocks), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold, \
-                       t->d_id_offset, t->d_hash_size, d_local_ids, d_in_gids, d_fields, batch, total, t->dim, d_gids, d_que, \
+                       t->d_id_offset, t->d_hash_size, d_local_ids, d_in_gids, d_fields, batch, total, t->dim, t->hotn, d_gids, d_que, \
                        d_out, (const float *)nullptr, 1, (const DevState *)nullptr, 0, (int32_t *)nullptr)
     if (t->timing) (void)hipEventRecord(t->ev_t[0][0], st);
     switch (lpg) {
@@ -258,11 +276,12 @@ extern "C" int cafe_forward_ml_dev(cafe_sketch_t *s, cafe_tables_t *t, const int
     }
     const int total = (int)total_l;
     const int blocks = (int)std::min<long>(((long)total + 255) / 256, 256 * 16);
+    if (pair_ok(s, t, "cafe_forward_ml_dev")) return 1;
     FastMod fm1 = make_fastmod(s->n1);
     hipStream_t st = (hipStream_t)stream;
 #define CAFE_FWD(L)                                                                                                        \
     hipLaunchKernelGGL((k_forward<L, true>), dim3(blocks), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold,      \
-                       t->d_id_offset, t->d_hash_size, d_local_ids, nullptr, nullptr, batch, total, t->dim, d_gids, d_que, \
+                       t->d_id_offset, t->d_hash_size, d_local_ids, nullptr, nullptr, batch, total, t->dim, t->hotn, d_gids, d_que, \
                        d_out, d_w_median, median_n, s->d_state, s->flip, d_qmed)
     switch (lanes_per_row(t->dim)) {
         case 1: CAFE_FWD(1); break;
@@ -470,7 +489,7 @@ __global__ void k_migrate(const MainBucket *__restrict__ mt, FastMod fm1, float 
                           const int64_t *__restrict__ id_offset,
                           const int64_t *__restrict__ local_ids, const int32_t *__restrict__ gids,
                           const int32_t *__restrict__ fields,
-                          const int32_t *__restrict__ ins, int batch, int begin, int total, int dim) {
+                          const int32_t *__restrict__ ins, int batch, int begin, int total, int dim, int hotn) {
     int i = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total || !ins[i]) return;
     const uint32_t x = (uint32_t)gids[i];
@@ -481,7 +500,7 @@ __global__ void k_migrate(const MainBucket *__restrict__ mt, FastMod fm1, float 
     const int64_t local = local_ids ? local_ids[i] : (int64_t)gids[i] - id_offset[f];
     const int64_t src_row = local % (int64_t)hash_size[f];     // LOCAL id: sk_embedding_bag.py:207
     const float4 *src = reinterpret_cast<const float4 *>(w_cold[f] + (size_t)src_row * dim);
-    float4 *dst = reinterpret_cast<float4 *>(w_hot + (size_t)(-q) * dim);
+    float4 *dst = reinterpret_cast<float4 *>(w_hot + (size_t)hot_row(q, hotn) * dim);
     for (int c = 0; c < (dim >> 2); ++c) dst[c] = src[c];
 }
 
@@ -493,9 +512,10 @@ extern "C" int cafe_migrate_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_
     }
     const int begin = first_field * batch, total = (first_field + n_fields) * batch;
     if (total == begin) return 0;
+    if (pair_ok(s, t, "cafe_migrate_dev")) return 1;
     hipLaunchKernelGGL(k_migrate, dim3((total - begin + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_main,
                        make_fastmod(s->n1), t->d_w_hot, t->d_w_cold, t->d_hash_size, t->d_id_offset, d_local_ids, d_gids,
-                       nullptr, d_ins, batch, begin, total, t->dim);
+                       nullptr, d_ins, batch, begin, total, t->dim, t->hotn);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -503,9 +523,10 @@ extern "C" int cafe_migrate_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_
 extern "C" int cafe_migrate_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_fields,
                                     const int32_t *d_ins, int n, cafe_stream_t stream) {
     if (n <= 0) return 0;
+    if (pair_ok(s, t, "cafe_migrate_gid_dev")) return 1;
     hipLaunchKernelGGL(k_migrate, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_main,
                        make_fastmod(s->n1), t->d_w_hot, t->d_w_cold, t->d_hash_size, t->d_id_offset, nullptr, d_gids,
-                       d_fields, d_ins, 1, 0, n, t->dim);
+                       d_fields, d_ins, 1, 0, n, t->dim, t->hotn);
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -516,7 +537,7 @@ template <int LPG>
 __global__ void __launch_bounds__(256) k_migrate_list(const MainBucket *__restrict__ mt, FastMod fm1, float *__restrict__ w_hot,
                                                       float *const *__restrict__ w_cold, const int32_t *__restrict__ hash_size,
                                                       const int64_t *__restrict__ local_ids, const int32_t *__restrict__ gids,
-                                                      const int32_t *__restrict__ ins, int batch, int total, int dim,
+                                                      const int32_t *__restrict__ ins, int batch, int total, int dim, int hotn,
                                                       const uint32_t *__restrict__ gotcount, const uint32_t *__restrict__ gotlist) {
     CAFE_KWIN(2);
     const uint32_t count = *gotcount;
@@ -535,7 +556,7 @@ __global__ void __launch_bounds__(256) k_migrate_list(const MainBucket *__restri
         const int f = i / batch;
         const int64_t src_row = local_ids[i] % (int64_t)hash_size[f];     // LOCAL id: sk_embedding_bag.py:207
         const float4 *src = reinterpret_cast<const float4 *>(w_cold[f] + (size_t)src_row * dim);
-        float4 *dst = reinterpret_cast<float4 *>(w_hot + (size_t)(-q) * dim);
+        float4 *dst = reinterpret_cast<float4 *>(w_hot + (size_t)hot_row(q, hotn) * dim);
         for (int c = lig; c < (dim >> 2); c += LPG) dst[c] = src[c];
     }
 }
@@ -548,7 +569,7 @@ static int migrate_list(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_loc
     FastMod fm1 = make_fastmod(s->n1);
 #define CAFE_MIG(L)                                                                                                        \
     hipLaunchKernelGGL(k_migrate_list<L>, dim3(64), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold, t->d_hash_size, \
-                       d_local_ids, d_gids, d_ins, batch, total, t->dim, cnt, lst)
+                       d_local_ids, d_gids, d_ins, batch, total, t->dim, t->hotn, cnt, lst)
     switch (lanes_per_row(t->dim)) {
         case 1: CAFE_MIG(1); break;
         case 2: CAFE_MIG(2); break;
@@ -579,7 +600,7 @@ __device__ inline uint32_t row_key(const int32_t *__restrict__ fields, const int
                                    const int32_t *__restrict__ hash_size, const int64_t *__restrict__ cold_base, int hotn,
                                    int batch, int i) {
     const int32_t q = que[i];
-    if (q < 0) return (uint32_t)(-q) % (uint32_t)hotn;
+    if (q < 0) return hot_row(q, hotn);
     const int f = fields ? fields[i] : i / batch;
     return (uint32_t)hotn + (uint32_t)cold_base[f] + (uint32_t)q % (uint32_t)hash_size[f];
 }
@@ -968,6 +989,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
     const int total = F * batch;
     hipStream_t st = (hipStream_t)stream;
     if (total <= 0) return 0;
+    if (pair_ok(s, t, "cafe_backward_update_dev")) return 1;
     const bool cadence = per_field && F > 1;
     bool fuse = F <= kMaxSeg && s->opt_fuse_fields && !s->opt_serial && total <= cafe::kParMaxIds;
     if (fuse) {

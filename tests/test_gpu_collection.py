@@ -141,3 +141,24 @@ def test_per_field_cadence_edge_shapes(F, B, oracle_mod):
     assert not bad, bad[:3]
     assert coll.sketch.counters()["cadence_miss"] == 0
     _close(coll.weight_high.cpu().numpy(), cpu.w_hot, "hot table")
+
+
+def test_pairings_the_reference_would_alias_are_refused():
+    """a slot handed out by the sketch indexes a row of the hot table.  The reference aliases a slot beyond
+    the table (`abs(dic) % hot_nums`, sk_embedding_bag.py:134) and ids beyond 2^31 (negative routing words); here a
+    sketch larger than the hot table and id offsets outside [0, 2^31) are errors, not memory faults."""
+    from cafe_amd import _lib
+    from cafe_amd.collection import CafeEmbeddingCollection
+    from cafe_amd.sketch import HotSketch
+    eng = CafeEmbeddingCollection([1000, 1000], 16, 200, [100, 100], threshold=2)
+    ids = torch.randint(0, 1000, (2, 64), device="cuda")
+    eng.forward(ids)
+    small = eng.sketch
+    eng.sketch = HotSketch(300, 2, 1, 1.0, 1)
+    with pytest.raises(_lib.CafeError, match="hot table has 200 rows"):
+        eng.forward(ids)
+    eng.sketch.close()
+    eng.sketch = small
+    eng.forward(ids)
+    with pytest.raises(_lib.CafeError, match="id_offset"):
+        CafeEmbeddingCollection([10, 10], 16, 50, [5, 5], offsets=[0, 2 ** 31], threshold=2)
