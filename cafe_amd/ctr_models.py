@@ -17,8 +17,11 @@ the fused HIP launches.  Structure and initialisation follow the reference:
   True registers them.
 * No dense features (Avazu-shaped data): the root scripts hard-code 13 dense inputs (wdl.py:410, dcn.py:412); the
   `dense is None` handling is ArtifactEvaluation/models.py:57-58, :87-88, :127-128.
-* Table sizes: cafe_amd.config (dlrm_s_pytorch.py:1237-1242, :309-322); every field must be a sketch field
-  (n > 2000 * compress_rate, dlrm_s_pytorch.py:309), which holds for all configurations of BASELINE.json.
+* Table sizes: cafe_amd.config (dlrm_s_pytorch.py:1237-1242, :309-322).  A field is a sketch field when
+  n > 2000 * compress_rate (dlrm_s_pytorch.py:309); smaller fields get a plain full table, as the reference gives them
+  (dlrm_s_pytorch.py:323-343: nn.EmbeddingBag(n, m), U(-sqrt(1/max(n, 5)), +)), outside the fused path (stock torch
+  ops).  Global id offsets and hotn count every field (tot_nums, dlrm_s_pytorch.py:353 and :1237-1240).  cfg4
+  (compress_rate 0.1) has two such fields.
 
 Call order of a training step is the reference's (dlrm_s_pytorch.py:1640-1658): forward, loss.backward(),
 insert_grad (scores -> sketch insert -> migration), optimizer step; the embedding tables' SGD runs inside the fused
@@ -152,15 +155,32 @@ class CafeCTRModel(nn.Module):
         super().__init__()
         self.kind, self.dim, self.dense_dim = kind, int(dim), int(dense_dim)
         self.counts = [int(c) for c in counts]
-        small = [n for n in self.counts if not n > 2000 * compress_rate]
-        if small:
-            raise ValueError(f"fields with {small} ids are not sketch fields at compress_rate {compress_rate} "
-                             "(dlrm_s_pytorch.py:309); only sketch fields are supported")
+        F = len(self.counts)
+        self.sk_idx = [i for i, n in enumerate(self.counts) if n > 2000 * compress_rate]        # dlrm_s_pytorch.py:309
+        self.plain_idx = [i for i in range(F) if i not in set(self.sk_idx)]
+        if not self.sk_idx:
+            raise ValueError("no field is large enough to be a sketch field (dlrm_s_pytorch.py:309)")
         self.per_field_calls = per_field_calls
         self.hotn = cfg.hot_rows(self.counts, dim, compress_rate, hash_rate)
-        self.hash_sizes = cfg.cold_rows(self.counts, compress_rate, hash_rate)
-        self.embedding = CafeEmbeddingCollection(self.counts, dim, self.hotn, self.hash_sizes, threshold=threshold,
-                                                 adjust_thres=adjust_thres, alpha=alpha, device=device, seed=seed)
+        sk_counts = [self.counts[i] for i in self.sk_idx]
+        self.hash_sizes = cfg.cold_rows(sk_counts, compress_rate, hash_rate)
+        offsets = cfg.field_offsets(self.counts)[self.sk_idx]
+        self.embedding = CafeEmbeddingCollection(sk_counts, dim, self.hotn, self.hash_sizes, offsets=offsets,
+                                                 threshold=threshold, adjust_thres=adjust_thres, alpha=alpha, device=device,
+                                                 seed=seed)
+        rng = np.random.RandomState(seed + 17)
+        self.plain = nn.ModuleList()
+        for i in self.plain_idx:
+            n = self.counts[i]
+            e = nn.Embedding(n, dim)
+            b = np.sqrt(1 / max(n, 5))
+            with torch.no_grad():
+                e.weight.copy_(torch.from_numpy(rng.uniform(-b, b, size=(n, dim)).astype(np.float32)))
+            self.plain.append(e)
+        self._order = None
+        if self.plain_idx:
+            order = self.sk_idx + self.plain_idx
+            self._order = torch.tensor([order.index(i) for i in range(F)], dtype=torch.long)
         dev = self.embedding.device
         self.head = CafeCTRHead(kind, len(self.counts), dim, dense_dim, ln_bot, ln_top, seed, train_cross,
                                 interaction_itself)
@@ -171,12 +191,20 @@ class CafeCTRModel(nn.Module):
 
     def forward(self, dense, ids):
         """dense: [B, dense_dim] or None; ids: [F, B] int64 local ids on the device."""
-        emb = _Lookup.apply(self._anchor, self, ids)
+        if not self.plain_idx:
+            return self.head(dense, _Lookup.apply(self._anchor, self, ids))
+        sk = _Lookup.apply(self._anchor, self, ids[self.sk_idx].contiguous())
+        pl = torch.stack([e(ids[i]) for e, i in zip(self.plain, self.plain_idx)])
+        emb = torch.cat([sk, pl]).index_select(0, self._order.to(sk.device))
         return self.head(dense, emb)
+
+    def dense_parameters(self):
+        """What torch's optimizer updates: the head and the plain tables of fields too small for the sketch."""
+        return list(self.head.parameters()) + list(self.plain.parameters())
 
     def train_step(self, dense, ids, labels, optimizer, lr):
         """One step in the reference's order (dlrm_s_pytorch.py:1640-1658): forward, backward, insert_grad, SGD.
-        `optimizer` holds head.parameters(); the tables are updated by the fused backward.  Returns the loss."""
+        `optimizer` holds dense_parameters(); the sketch-backed tables are updated by the fused backward.  Returns the loss."""
         optimizer.zero_grad(set_to_none=True)
         p = self.forward(dense, ids)
         loss = self.loss_fn(p, labels)

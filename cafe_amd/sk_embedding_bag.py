@@ -104,14 +104,19 @@ class _RoutedGather(torch.autograd.Function):
     def forward(ctx, weight_h, weight_hash, mod, ids):
         ctx.mod = mod
         ctx.sizes = (weight_h.shape, weight_hash.shape)
-        return mod._launch_forward(ids)
+        out = mod._launch_forward(ids)
+        # the routing and ids of THIS forward: the module's own fields follow its latest forward, which may be another
+        # one (an evaluation between forward and backward, a second micro-batch)
+        ctx.que, ctx.ids, ctx.gids = mod._que, mod._ids, mod._gids
+        return out
 
     @staticmethod
     def backward(ctx, g):
         mod = ctx.mod
         g = g.contiguous()
         mod._grad_out = g                       # insert_grad scores this lookup by the norm of its own row (Q2)
-        que = mod._que
+        mod._grad_ids = (ctx.ids, ctx.gids)     # ... and feeds the sketch the ids this gradient belongs to
+        que = ctx.que
         hot = (que < 0)[:, None]
         dic = que.abs().to(torch.int64)
         zero = torch.zeros((), dtype=g.dtype, device=g.device)
@@ -147,6 +152,7 @@ class SKEmbeddingBag(nn.Module):
         self._que = None
         self._mask = None
         self._grad_out = None
+        self._grad_ids = None
         self.weight_hash = Parameter(torch.empty(self.hash_size, self.embedding_dim))
         self.reset_parameters()
 
@@ -263,7 +269,8 @@ class SKEmbeddingBag(nn.Module):
         g = self._grad_out
         if g is None:
             raise _lib.CafeError("insert_grad: no gradient recorded -- call loss.backward() after forward first")
-        n = self._gids.numel()
+        ids, gids = self._grad_ids
+        n = gids.numel()
         if n == 0:
             return
         t = self._get_tables()
@@ -272,11 +279,11 @@ class SKEmbeddingBag(nn.Module):
         st = _stream()
         with _Timed():
             _lib.check(self._L.cafe_scores_dev(t, _p(g), n, _p(scores), st), "cafe_scores_dev")
-            _lib.check(self._L.cafe_insert_dev(self._sketch(), _p(self._gids), _p(scores), n, _p(ins), st), "cafe_insert_dev")
-            _lib.check(self._L.cafe_migrate_dev(self._sketch(), t, _p(self._ids), _p(self._gids), _p(ins), n, 0, 1, st),
+            _lib.check(self._L.cafe_insert_dev(self._sketch(), _p(gids), _p(scores), n, _p(ins), st), "cafe_insert_dev")
+            _lib.check(self._L.cafe_migrate_dev(self._sketch(), t, _p(ids), _p(gids), _p(ins), n, 0, 1, st),
                        "cafe_migrate_dev")
         self._scores, self._ins = scores, ins
-        self._grad_out = None
+        self._grad_out = self._grad_ids = None
 
     def extra_repr(self):
         return f"{self.num_categories}, {self.embedding_dim}, hot={self.hot_nums}, hash_size={self.hash_size}, offset={self.offset}"

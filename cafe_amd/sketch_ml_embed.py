@@ -38,13 +38,15 @@ class _RoutedGatherML(torch.autograd.Function):
     def forward(ctx, weight_h, weight_hash, weight_median, mod, ids, test):
         ctx.mod = mod
         ctx.sizes = (weight_h.shape, weight_hash.shape, weight_median.shape)
-        return mod._launch_forward(ids, test)
+        out = mod._launch_forward(ids, test)
+        ctx.que, ctx.qmed = mod._que, mod._qmed      # this forward's routing (the module's fields follow its latest forward)
+        return out
 
     @staticmethod
     def backward(ctx, g):
         mod = ctx.mod
         g = g.contiguous()
-        que, qmed = mod._que, mod._qmed
+        que, qmed = ctx.que, ctx.qmed
         hot = (que < 0)[:, None]
         med = (~hot) & (qmed < 0)[:, None]
         dic = que.abs().to(torch.int64)

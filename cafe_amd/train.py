@@ -50,10 +50,16 @@ def parse(argv=None):
     return p.parse_args(argv)
 
 
-def synthetic_batches(w, dense_dim, num_batches, seed, device):
+def synthetic_batches(w, dense_dim, num_batches, seed, device, start=0):
     rng = np.random.default_rng(seed)
-    for _ in range(num_batches):
-        ids = torch.from_numpy(w.make_ids(int(rng.integers(1 << 31)), 1)[0]).to(device)
+    for k in range(num_batches):
+        id_seed = int(rng.integers(1 << 31))
+        if k < start:           # resumed run: the generator advances exactly as if the batch had been produced
+            if dense_dim:
+                rng.random((w.batch, dense_dim), dtype=np.float32)
+            rng.random((w.batch, 1))
+            continue
+        ids = torch.from_numpy(w.make_ids(id_seed, 1)[0]).to(device)
         x = torch.from_numpy(rng.random((w.batch, dense_dim), dtype=np.float32)).to(device) if dense_dim else None
         y = torch.from_numpy((rng.random((w.batch, 1)) < 0.25).astype(np.float32)).to(device)
         yield x, ids, y
@@ -62,7 +68,8 @@ def synthetic_batches(w, dense_dim, num_batches, seed, device):
 def save_checkpoint(path, model, step):
     """Model parameters + tables + the complete sketch state (every slot, scalars, free list)."""
     emb = model.embedding
-    torch.save({"step": int(step), "head": model.head.state_dict(), "weight_high": emb.weight_high.cpu(),
+    torch.save({"step": int(step), "head": model.head.state_dict(), "plain": model.plain.state_dict(),
+                "weight_high": emb.weight_high.cpu(),
                 "weight_hash": [w.cpu() for w in emb.weight_hash], "sketch": emb.sketch.state_tensors()}, path)
 
 
@@ -70,6 +77,8 @@ def load_checkpoint(path, model):
     ck = torch.load(path, map_location="cpu", weights_only=True)
     emb = model.embedding
     model.head.load_state_dict(ck["head"])
+    if "plain" in ck:
+        model.plain.load_state_dict(ck["plain"])
     emb.weight_high.copy_(ck["weight_high"])
     for w, src in zip(emb.weight_hash, ck["weight_hash"]):
         w.copy_(src)
@@ -114,15 +123,19 @@ def main(argv=None):
     model = CafeCTRModel(a.model, counts, dim, dense_dim=dense_dim, compress_rate=cr, hash_rate=hr, threshold=thr,
                          adjust_thres=a.adjust_threshold, alpha=a.sketch_alpha, ln_bot=ln_bot, ln_top=ln_top, device=dev,
                          seed=a.numpy_rand_seed, per_field_calls=not a.fused_insert)
-    opt = torch.optim.SGD(model.head.parameters(), lr=a.learning_rate)
+    opt = torch.optim.SGD(model.dense_parameters(), lr=a.learning_rate)
     step0 = load_checkpoint(a.load_model, model) if a.load_model else 0
     print(json.dumps({"model": a.model, "fields": len(counts), "dim": dim, "batch": batch, "hotn": model.hotn,
                       "cold_rows": int(sum(model.hash_sizes)), "ids": int(sum(counts)), "start_step": step0}), flush=True)
     step, run_loss, run_n, t0 = step0, None, 0, time.time()
-    for epoch in range(a.nepochs):
-        it = (train.batches(batch, dev) if files
-              else synthetic_batches(w, dense_dim, a.num_batches, a.numpy_rand_seed + epoch, dev))
-        for j, (x, ids, y) in enumerate(it):
+    # a resumed run continues at the saved iteration of the saved epoch (dlrm_s_pytorch.py:1512-1525 ld_k, ld_j)
+    per_epoch = a.num_batches if a.num_batches else ((len(train) + batch - 1) // batch if files else 0)
+    epoch0, skip = (step0 // per_epoch, step0 % per_epoch) if per_epoch else (0, 0)
+    for epoch in range(epoch0, a.nepochs):
+        first = skip if epoch == epoch0 else 0
+        it = (train.batches(batch, dev, start=first) if files
+              else synthetic_batches(w, dense_dim, a.num_batches, a.numpy_rand_seed + epoch, dev, start=first))
+        for j, (x, ids, y) in enumerate(it, start=first):
             if a.num_batches and j >= a.num_batches:
                 break
             loss = model.train_step(x, ids, y, opt, a.learning_rate)

@@ -113,3 +113,45 @@ def test_sketch_state_travels_with_a_checkpoint(tmp_path):
         assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), k
     for k in ("thr", "num", "real_n", "clk", "flip", "batch_num", "decay"):
         assert got[k] == want[k], k
+
+
+def test_evaluation_between_forward_and_backward_does_not_change_the_step():
+    """backward and insert_grad belong to the forward that produced the gradient, not to the module's
+    latest forward.  Two identical modules take the same training step; one of them evaluates another batch (of
+    another size) under no_grad between its forward and its backward.  Gradients, sketch state and tables must agree."""
+    import cafe_amd
+    from cafe_amd.sk_embedding_bag import SKEmbeddingBag
+    from cafe_amd.sketch import HotSketch
+    dev = torch.device("cuda", 0)
+    hotn, D, n, hs = 200, 16, 5000, 37
+    rng = np.random.default_rng(3)
+    train_ids = torch.from_numpy((rng.zipf(1.2, 256) % n).astype(np.int64))
+    eval_ids = torch.from_numpy((rng.zipf(1.2, 100) % n).astype(np.int64))
+    results = []
+    for interleave in (False, True):
+        sk = HotSketch(hotn, 2, 1, 1.0, 1)
+        wh = torch.nn.Parameter(torch.zeros(hotn, D, device=dev))
+        e = SKEmbeddingBag(0, hotn, sk, wh, dev, n, D, 0, hs).to(dev)
+        with torch.no_grad():
+            e.weight_hash.copy_(torch.linspace(-1, 1, hs * D, device=dev).view(hs, D))
+        for step in range(3):
+            out = e(train_ids, torch.arange(256))
+            if interleave:
+                with torch.no_grad():
+                    e(eval_ids, torch.arange(100))
+            (out * out).sum().backward()
+            e.insert_grad(train_ids)
+            with torch.no_grad():
+                for p in (wh, e.weight_hash):
+                    p.add_(p.grad.to_dense(), alpha=-0.05)
+                    p.grad = None
+        st = sk.state()
+        results.append((st, wh.detach().cpu().numpy(), e.weight_hash.detach().cpu().numpy()))
+    (sa, ha, ca), (sb, hb, cb) = results
+    for k in ("mval", "mdic", "lval", "ldic", "lt", "fifo"):
+        assert np.array_equal(np.asarray(sa[k]), np.asarray(sb[k])), k
+    # (torch's sparse -> dense sums duplicate rows in no fixed order: floats agree to rounding, not bit for bit)
+    for a, b, what in ((sa["mcnt"], sb["mcnt"], "main scores"), (sa["lcnt"], sb["lcnt"], "LRU scores"), (ha, hb, "hot table"),
+                       (ca, cb, "cold table")):
+        _close(a, b, what)
+    assert (np.asarray(sa["mdic"]) != 0).sum() > 5
