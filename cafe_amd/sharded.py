@@ -143,6 +143,7 @@ class ShardedCafeEmbedding:
         got = self._a2a(packed, ss, rs)
         r_gids = (got & 0xFFFFFFFF).to(torch.int32)          # wraps to the int32 bit pattern
         r_fields = (got >> 32).to(torch.int32)
+        self.last_received = int(r_gids.numel())
         que, rows = self.backend.forward_gid(r_gids, r_fields)
         back = self._a2a(rows, rs, ss)
         if out is None:

@@ -1,0 +1,76 @@
+"""Turns the outputs of tools/profile_round.sh into the committed summaries:
+
+    python tools/profile_collect.py r02
+
+  profiles/<tag>_bench_cfg3_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary (per kernel: calls, total, average)
+  profiles/<tag>_pmc_fetch_size_summary.txt      mean FETCH_SIZE per launch and kernel (KiB as reported)
+  profiles/<tag>_pmc_write_size_summary.txt      mean WRITE_SIZE per launch and kernel
+  profiles/traffic.json                          HBM bytes per launch of the two bandwidth kernels, corrected as
+                                                 MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled on gfx950 for 16-B-per-
+                                                 lane reads, WRITE_SIZE as is), calibration lines included"""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+
+
+def find(d, pat):
+    f = glob.glob(os.path.join(root, "gpurun_out", d, "**", pat), recursive=True)
+    if not f:
+        sys.exit(f"missing {d}/{pat}")
+    return f[0]
+
+
+shutil.copy(find(f"{tag}_stats", "*kernel_stats.csv"), os.path.join(out, f"{tag}_bench_cfg3_kernel_stats.csv"))
+
+
+def pmc(d, counter):
+    per = defaultdict(list)
+    for r in csv.DictReader(open(find(d, "*counter_collection.csv"))):
+        if r["Counter_Name"] == counter:
+            per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    res = {}
+    for k, v in per.items():
+        tail = v[len(v) // 2:]                     # steady state: the last half of the launches
+        res[k] = (sum(tail) / len(tail), len(v))
+    return res
+
+
+def write_summary(res, counter, path):
+    with open(path, "w") as f:
+        f.write(f"{'kernel':50s} {counter:>12s}   calls\n")
+        for k, (m, n) in sorted(res.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            f.write(f"{k[:46]:50s} {m:12.0f}   {n}\n")
+
+
+fetch, write = pmc(f"{tag}_fetch", "FETCH_SIZE"), pmc(f"{tag}_write", "WRITE_SIZE")
+write_summary(fetch, "FETCH_SIZE", os.path.join(out, f"{tag}_pmc_fetch_size_summary.txt"))
+write_summary(write, "WRITE_SIZE", os.path.join(out, f"{tag}_pmc_write_size_summary.txt"))
+
+
+def pick(res, prefix):
+    for k, v in res.items():
+        name = k.replace("void ", "").replace("cafe::", "")
+        if name.startswith(prefix):
+            return v[0]
+    return None
+
+
+F, B, D = 26, 8192, 128
+alg = {"k_forward": F * B * (56 + 8 * D), "k_bwd_segments": F * B * 12 * D, "k_grad_norm": F * B * (4 * D + 4)}
+tj = {"workload": "cfg3/b8192",
+      "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/profile_round.sh {tag}) of `bench.py --steps 6 "
+                "--warmup 2 --preheat 30`, per-launch mean of the last half of the launches; FETCH_SIZE is in KiB and doubled (gfx950 "
+                "tallies 128-B requests at 64 B for 16-B-per-lane reads, MI355X_MICROARCH.md HBM section; calibration: k_grad_norm reads "
+                "exactly 109.05 MB), WRITE_SIZE in KiB taken as is (calibration: k_forward writes 109.05 MB + 1.7 MB)"}
+for k in ("k_forward", "k_bwd_segments", "k_grad_norm"):
+    fk, wk = pick(fetch, k), pick(write, k)
+    if fk is None or wk is None:
+        continue
+    rd, wr = int(fk * 1024 * 2), int(wk * 1024)
+    tj[k] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "total": rd + wr, "algorithmic": alg[k],
+             "fetch_size_kib_reported": round(fk), "write_size_kib_reported": round(wk)}
+json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+print(json.dumps(tj, indent=1))
