@@ -1055,6 +1055,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             if (cafe::last_insert_verdict(s, &rejected, &reason)) return 1;
             s->host_us[1] += t_wait - t_begin; s->host_us[2] += now_us() - t_wait; s->host_us[3] += 1;
             if (!rejected) { s->force_cap_once = 0; return 0; }
+            if (reason == 4) s->inner_reset_rejects++;
             // nothing was applied on the device: take the call counters back as well
             s->decay = decay0;
             s->batch_num = batch_num0;

@@ -126,6 +126,7 @@ struct Geo {
     int sseg;                   // > 0: ids per field for the score scaling (Score::psum)
     int nparts;                 // partial sums per field behind Score::psum
     int prof;                   // diagnostic builds: stamp slot of the kernel
+    int cap_ev;                 // moves one main partition accepts per round (<= kCapEv; smaller in tests)
     FastMod fm1, fm2;
 };
 
@@ -954,7 +955,7 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
     int ne = 0;
     if (MOVES) {
         const uint32_t ne_raw = A.evcnt[prev * g.P1 + p];
-        if (ne_raw > (uint32_t)kCapEv) { if (tid == 0) A.ctl->overflow = 1; return; }
+        if (ne_raw > (uint32_t)g.cap_ev) { if (tid == 0) A.ctl->overflow = 1; return; }
         ne = (int)ne_raw;
     }
     const int total = np + ne;
@@ -1304,7 +1305,7 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *n_ev, int *s_total, 
             const MoveEv m = mine_ev[j];
             const int p = m.pad[0];
             uint32_t at = atomicAdd(&A.evcnt[par * g.P1 + p], 1u);
-            if (at < (uint32_t)kCapEv) A.ev[(size_t)par * g.P1 * kCapEv + (size_t)p * kCapEv + at] = m; else A.ctl->overflow = 1;
+            if (at < (uint32_t)g.cap_ev) A.ev[(size_t)par * g.P1 * kCapEv + (size_t)p * kCapEv + at] = m; else A.ctl->overflow = 1;
         }
         return;
     }
@@ -1386,7 +1387,7 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *n_ev, int *s_total, 
                 m.time = 2u * pos + 1u; m.x = mv.x; m.cnt = mv.cnt; m.dic = mv.dic; m.kind = mv.kind;
                 m.pad[0] = p; m.pad[1] = m.pad[2] = 0;
                 uint32_t at = atomicAdd(&A.evcnt[par * g.P1 + p], 1u);
-                if (at < (uint32_t)kCapEv) A.ev[(size_t)par * g.P1 * kCapEv + (size_t)p * kCapEv + at] = m; else over = 1;
+                if (at < (uint32_t)g.cap_ev) A.ev[(size_t)par * g.P1 * kCapEv + (size_t)p * kCapEv + at] = m; else over = 1;
                 int mi = atomicAdd(n_ev, 1);
                 if (mi < kCapEvL) mine_ev[mi] = m; else over = 1;
             }
@@ -1902,6 +1903,7 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     g.bits1 = ilog2_ceil(g.bpp1);
     g.bits2 = ilog2_ceil(g.bpp2);
     g.nchunks = (n + kChunk - 1) / kChunk;
+    g.cap_ev = std::min(std::max(s->opt_move_cap, 1), kCapEv);
     // hot list: partitions small enough for the per-wave slot table if the plan's histogram has room for them, else
     // the main table's partitions (sorted by the owner)
     g.hot = s->opt_hot_bypass ? 1 : 0;

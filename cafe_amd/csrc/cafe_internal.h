@@ -51,7 +51,8 @@ struct cafe_sketch {
     uint32_t fifo_cap = 1;
     cafe::DevState *d_state = nullptr;
     // options / counters
-    int opt_serial = 0, opt_max_rounds = 6, opt_target_items = 320, opt_hot_bypass = 1, opt_hot_table = 0;
+    int opt_serial = 0, opt_max_rounds = 6, opt_target_items = 320, opt_hot_bypass = 1, opt_hot_table = 0, opt_move_cap = 1 << 20;
+    int64_t inner_reset_rejects = 0;     // fused steps the device rejected because sketch.cpp:291 fired at an inner field boundary
     int force_cap = 0;                  // option "owner_cap": items an owner workgroup can hold (0 = chosen per call)
     int force_cap_once = 0;             // ... for the call being issued (a step issued again after a workspace limit)
     int score_seg = 0;                  // > 0: vals are norms, scaled per segment of score_seg ids (ScoreSrc)

@@ -415,6 +415,7 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
     else if (!strcmp(name, "exact_reset")) (void)value;          // kept for callers of older builds: the decision is always exact
     else if (!strcmp(name, "hot_table")) s->opt_hot_table = value ? 1 : 0;
     else if (!strcmp(name, "plan_ahead")) s->opt_plan_ahead = value ? 1 : 0;
+    else if (!strcmp(name, "move_cap")) s->opt_move_cap = value;
     else if (!strcmp(name, "owner_cap")) s->force_cap = value == 1024 || value == 2048 || value == 8192 ? value : 0;
     else if (!strcmp(name, "overlap")) s->opt_overlap = value;
     else if (!strcmp(name, "fuse_fields")) s->opt_fuse_fields = value ? 1 : 0;
@@ -425,10 +426,11 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
 
 static int read_state(cafe_sketch *s, DevState *h);
 
-extern "C" int cafe_sketch_fallback_reasons(cafe_sketch_t *s, int64_t *out3) {
+extern "C" int cafe_sketch_fallback_reasons(cafe_sketch_t *s, int64_t *out4) {
     DevState h;
     if (read_state(s, &h)) return 1;
-    for (int i = 0; i < 3; ++i) out3[i] = h.why[i];
+    for (int i = 0; i < 3; ++i) out4[i] = h.why[i];
+    out4[3] = s->inner_reset_rejects;
     return 0;
 }
 

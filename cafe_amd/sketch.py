@@ -103,9 +103,10 @@ class HotSketch:
         names = ("insert_calls", "parallel_calls", "inorder_calls", "rounds_total", "resets", "rounds_max", "cadence_miss",
                  "exact_waits")
         d = dict(zip(names, (int(x) for x in out)))
-        why = (ctypes.c_int64 * 3)()
+        why = (ctypes.c_int64 * 4)()
         self.L.cafe_sketch_fallback_reasons(self.h, why)
         d["left_parallel_path"] = {"workspace_limit": int(why[0]), "rounds_not_settled": int(why[1]), "free_list": int(why[2])}
+        d["inner_reset_rejects"] = int(why[3])
         ren = ctypes.c_int64()
         self.L.cafe_sketch_clock_renorms(self.h, ctypes.byref(ren))
         d["clock_renorms"] = int(ren.value)

@@ -104,10 +104,13 @@ int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int value);
  * boundaries at which the reference would have reset but the host's estimate of real_n said no (expected 0; the
  * reset then happens at the next boundary), [7] times the host waited for the exact real_n. */
 int cafe_sketch_counters(cafe_sketch_t *s, int64_t *out8);
-/* Why batches left the parallel path (given to the in-order kernel, or rejected in verify mode), since creation:
- * [0] a workspace limit (partition larger than an owner can sort, move list full, clock range), [1] the fix-point
- * rounds that were enqueued did not settle the batch, [2] the free list ran dry or was refilled inside the batch. */
-int cafe_sketch_fallback_reasons(cafe_sketch_t *s, int64_t *out3);
+/* Why batches left the parallel path (given to the in-order kernel, or -- cafe_backward_update_dev -- rejected before
+ * anything was applied and issued again), since creation: [0] a workspace limit (partition larger than an owner can
+ * sort, move list full, clock range), [1] the fix-point rounds that were enqueued did not settle the batch, [2] the
+ * free list ran dry or was refilled inside the batch, [3] fused steps rejected because the reset test of
+ * sketch.cpp:291 fired at an inner field boundary (such a step is then issued field by field; this is how the
+ * per-field reset cadence stays exact, not a failure). */
+int cafe_sketch_fallback_reasons(cafe_sketch_t *s, int64_t *out4);
 /* Lifetime of the LRU clock (sketch.cpp:17 `t`, one tick per main-table miss): the reference's victim search starts
  * from the constant 1e9 (sketch.cpp:159) and its int clock wraps at 2^31, so it is undefined from 1e9 ticks on (about
  * 10^4 Criteo-Terabyte steps).  Only the order of the four timestamps inside an LRU bucket matters; when the clock

@@ -162,3 +162,111 @@ def test_pairings_the_reference_would_alias_are_refused():
     eng.forward(ids)
     with pytest.raises(_lib.CafeError, match="id_offset"):
         CafeEmbeddingCollection([10, 10], 16, 50, [5, 5], offsets=[0, 2 ** 31], threshold=2)
+
+
+def _run_steps(coll, cpu, oracle_mod, batches, grads, lr=0.05, check_tables=True):
+    """forward + backward_update(per_field) on both sides; ins[] compared every step, state and tables at the end."""
+    F = coll.F
+    deltas = []
+    for step, (ids, grad) in enumerate(zip(batches, grads)):
+        B = ids.shape[1]
+        before = cpu.sk.state()["real_n"]
+        coll.forward(torch.from_numpy(ids).cuda())
+        cpu.forward(ids)
+        scores, ins = coll.backward_update(grad, lr, per_field_calls=True)
+        sc = scores.cpu().numpy().reshape(F, B)
+        ins_want = cpu.backward_update(ids, grad.cpu().numpy(), sc, lr, True)
+        assert np.array_equal(ins.cpu().numpy().reshape(F, B), ins_want), f"step {step}: ins differs"
+        deltas.append(cpu.sk.state()["real_n"] - before)
+    bad = oracle_mod.states_equal(coll.sketch.state(), cpu.sk.state())
+    assert not bad, bad[:3]
+    if check_tables:
+        _close(coll.weight_high.cpu().numpy(), cpu.w_hot, "hot table")
+        for f in range(F):
+            _close(coll.weight_hash[f].cpu().numpy(), cpu.w_cold[f], f"cold table {f}")
+    return deltas
+
+
+def test_crossing_burst_fires_the_reset_at_an_inner_field_boundary(oracle_mod):
+    """the per-field reset cadence (sketch.cpp:291 at the start of every per-field call) must be
+    exact by construction, not by an estimate of the crossing rate.  A quiet stream (a few tens of threshold crossings
+    per step) brings real_n close to 1.2 lim; then ONE step brings more than 20 times as many crossings, spread over all
+    fields, so the reset is due at an inner field boundary of a step that is running as one fused insert.  The device
+    must reject that step before applying anything and the host must issue it field by field: ins[], every slot,
+    scalars and the free list equal the oracle's per-field calls."""
+    from cafe_amd.collection import CafeEmbeddingCollection
+    F, B, dim, lim, thr = 8, 4096, 16, 3000, 2
+    counts = [100000] * F
+    hash_sizes = [499] * F
+    coll = CafeEmbeddingCollection(counts, dim, lim, hash_sizes, threshold=thr, adjust_thres=1, alpha=1.0000005, seed=5)
+    cpu = _CpuPipeline(oracle_mod, coll, thr, 1, 1.0000005)
+    rng = np.random.default_rng(17)
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    fresh = [50000]                                   # ids >= 50000 are never drawn by the base stream
+
+    def batch(pairs_per_field):
+        ids = np.stack([(rng.zipf(1.3, size=B) - 1) % 300 for _ in range(F)]).astype(np.int64)
+        ids[0] = np.maximum(ids[0], 1)
+        grad = torch.randn(F, B, dim, device="cuda", generator=gen)
+        for f in range(F):
+            at = rng.choice(B // 2, size=pairs_per_field, replace=False) * 2
+            new = np.arange(fresh[0], fresh[0] + pairs_per_field)
+            fresh[0] += pairs_per_field
+            ids[f, at] = new; ids[f, at + 1] = new            # a new id twice in a row: placed with score 1, then pushed
+            grad[f, torch.from_numpy(np.concatenate([at, at + 1])).cuda()] *= 6.0       # over the threshold (2) by a score > 1
+        return ids, grad
+
+    for _ in range(12):
+        _run_steps(coll, cpu, oracle_mod, *[[x] for x in batch(0)], check_tables=False)
+    # the approach: 5 pairs per field and step until real_n is within 150 of the reset level
+    quiet = []
+    for _ in range(400):
+        if 1.2 * lim - 150 <= cpu.sk.state()["real_n"] <= 1.2 * lim - 60:
+            break
+        quiet += _run_steps(coll, cpu, oracle_mod, *[[x] for x in batch(5)], check_tables=False)
+    else:
+        pytest.fail("real_n never came close to the reset level")
+    rejects0 = coll.sketch.counters()["inner_reset_rejects"]
+    resets0 = cpu.sk.state()["resets"]
+    trailing = max(1, max(quiet[-8:]))
+    burst_pairs = 150
+    assert F * burst_pairs >= 20 * trailing, (trailing, F * burst_pairs)
+    _run_steps(coll, cpu, oracle_mod, *[[x] for x in batch(burst_pairs)])
+    c = coll.sketch.counters()
+    assert cpu.sk.state()["resets"] == resets0 + 1            # the oracle reset inside the burst step ...
+    assert c["inner_reset_rejects"] == rejects0 + 1, c         # ... and the fused step was rejected and reissued
+    assert c["cadence_miss"] == 0
+    for _ in range(3):
+        _run_steps(coll, cpu, oracle_mod, *[[x] for x in batch(5)])
+
+
+@pytest.mark.parametrize("option,value,reason,hotn", [
+    ("max_rounds", 1, "rounds_not_settled", 1200),
+    ("move_cap", 1, "workspace_limit", 1200),
+    (None, 0, "free_list", 150),
+], ids=["rounds", "move_list", "free_list"])
+def test_fused_steps_that_the_device_rejects_stay_exact(option, value, reason, hotn, oracle_mod):
+    """every reason for leaving the parallel path, forced inside fused steps (the device rejects the
+    step before applying anything; the host issues it again with the largest owners, then call by call): too few
+    rounds enqueued, the move list of a main partition full, the free list running dry inside the batch."""
+    from cafe_amd.collection import CafeEmbeddingCollection
+    F, B, dim, thr = 4, 2048, 16, 2
+    counts = [40000, 9000, 70000, 3000]
+    hash_sizes = [211, 37, 499, 13]
+    coll = CafeEmbeddingCollection(counts, dim, hotn, hash_sizes, threshold=thr, adjust_thres=1, alpha=1.0000005, seed=6)
+    if option:
+        coll.sketch.set_option(option, value)
+    cpu = _CpuPipeline(oracle_mod, coll, thr, 1, 1.0000005)
+    rng = np.random.default_rng(23)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    batches, grads = [], []
+    for step in range(14):
+        ids = np.stack([(rng.zipf(1.15, size=B) - 1 + step * 11) % c for c in counts]).astype(np.int64)
+        ids[0] = np.maximum(ids[0], 1)
+        g = torch.randn(F, B, dim, device="cuda", generator=gen)
+        g[:, ::3] *= 8.0                      # large scores: evicted LRU entries qualify for a move (sketch.cpp:193-195)
+        batches.append(ids); grads.append(g)
+    _run_steps(coll, cpu, oracle_mod, batches, grads)
+    c = coll.sketch.counters()
+    assert c["left_parallel_path"][reason] > 0, c
+    assert c["cadence_miss"] == 0

@@ -174,7 +174,8 @@ def test_reference_abi_drop_in():
     assert "ABI_OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("option,value,reason", [("max_rounds", 1, "rounds_not_settled"), ("target_items", 16, None)])
+@pytest.mark.parametrize("option,value,reason", [("max_rounds", 1, "rounds_not_settled"), ("target_items", 16, None),
+                                                 ("move_cap", 1, "workspace_limit")])
 def test_batches_that_leave_the_parallel_path_stay_exact(option, value, reason, oracle_mod):
     """Too few rounds enqueued to settle a batch (max_rounds = 1), or an unusual partition size: the batch goes to the
     in-order kernel untouched (or runs with other partitions) -- never a different result -- and the reason is
