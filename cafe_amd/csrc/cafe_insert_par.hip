@@ -56,10 +56,11 @@ constexpr int kCapEv = 512;           // moves one main partition can receive pe
 constexpr int kCapEvL = 1024;         // moves one LRU partition can emit per round (an item emits at most one)
 constexpr int kMaxRounds = 16;
 constexpr int kHeavySeg = 4;          // a bucket with at least this many items in the batch is replayed by a whole wave
+constexpr int kLruHeavy = 32;         // an LRU bucket with at least this many items in the batch is replayed by a whole wave
 constexpr int kMaxHeavy = 64;         // heavy buckets one partition can hand to its waves (more: replayed by single lanes)
 constexpr int kScanBlock = 1024;
 constexpr int kDigitBits = 10, kDigits = 1 << kDigitBits;
-constexpr int kFixGrid = 64;          // workgroups of the persistent fix-point kernel
+constexpr int kFixGrid = 64;          // workgroups of the persistent fix-point kernel (more when many partitions are in play)
 
 constexpr uint32_t kSur = 0x80000000u;      // placeholder for "slot popped by item (v & 0x7fffffff)"
 constexpr uint32_t kMissBit = 0x80000000u;  // Rec::bl: the id is not in its main bucket before the batch
@@ -1287,8 +1288,8 @@ struct LruArgs {
 // Replays the items of LRU partition q that missed the main table (round 1: the presumed misses of the plan), in
 // batch order per bucket, and hands every move out of the table to the main partition of its target bucket.
 template <int CAP, bool MV>
-__device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *n_ev, int *s_total, float *fsum, const Geo &g, int q, int round,
-                                 const LruArgs &A, const Score &sc) {
+__device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, int *n_ev, int *s_total, float *fsum, const Geo &g,
+                                 int q, int round, const LruArgs &A, const Score &sc) {
     const int tid = threadIdx.x;
     const int par = round & 1, nxt = par ^ 1;
     const uint32_t o0 = A.off[off_lru0(g) + q], o1 = A.off[off_lru0(g) + q + 1];
@@ -1309,7 +1310,7 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *n_ev, int *s_total, 
         }
         return;
     }
-    if (tid == 0) *n_ev = 0;
+    if (tid == 0) { *n_ev = 0; *n_hv = 0; }
     if (cnt == 0) { if (tid == 0) { A.stage_tot[g.P1 + q] = 0; A.mycnt[q] = 0; } return; }
     CAFE_STAMP_VAL(g.prof, 7, 2ull | ((unsigned long long)cnt << 8));
     field_sums(g, sc, fsum);
@@ -1364,6 +1365,12 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *n_ev, int *s_total, 
     for (int s = tid; s < nmiss; s += kThreads) {
         const uint32_t bl = L.s.sg[s];
         if (s != 0 && L.s.sg[s - 1] == bl) continue;
+        // a bucket with many items (an id that is frequent but not hot yet: it lives here until its score reaches the
+        // threshold) is left to phase B, where a whole wave walks it
+        if (s + kLruHeavy <= nmiss && L.s.sg[s + kLruHeavy - 1] == bl) {
+            const int at = atomicAdd(n_hv, 1);
+            if (at < kMaxHeavy) { heavy[at] = s; continue; }
+        }
         LruR b;
         load_lru(b, &A.lt[b0 + (int)bl]);
         sync_flip(b, gflip);
@@ -1395,6 +1402,76 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *n_ev, int *s_total, 
         store_lru(&stage[s], b, b0 + (int)bl);
     }
     __syncthreads();
+    // Phase B: heavy buckets, one per wave at a time; all 64 lanes carry the same bucket copy.  A run of probes of one id
+    // that sits in the bucket and stays below the threshold only moves its score (ordered float sum: one readlane + add
+    // per item) and its timestamp; the first probe that reaches the threshold, and every miss, takes the one-item step
+    // (sketch.cpp:165-209), executed uniformly with lane 0 writing.
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int nh = min(*n_hv, kMaxHeavy);
+        for (int h = wave; h < nh; h += kWaves) {
+            const int s = heavy[h];
+            const uint32_t bl = L.s.sg[s];
+            LruR b;
+            load_lru(b, &A.lt[b0 + (int)bl]);
+            sync_flip(b, gflip);
+            int e = s;
+            while (e < nmiss && L.s.sg[e] == bl) {
+                const uint32_t x = L.s.px[e];
+                const int f = lru_find(b, x);
+                if (f >= 0) {
+                    const int idx = e + lane;
+                    const bool same = idx < nmiss && L.s.sg[idx] == bl && L.s.px[idx] == x;
+                    const unsigned long long m = __ballot(same);
+                    const int r = (~m) ? __builtin_ctzll(~m) : 64;            // length of the run starting at e (>= 1)
+                    const float c = lane < r ? L.s.pc[idx] : 0.0f;
+                    float acc = sel4f(b.c0, b.c1, b.c2, b.c3, f), mine = 0.0f;
+                    for (int j = 0; j < r; ++j) {
+                        acc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), j));
+                        mine = lane == j ? acc : mine;
+                    }
+                    const unsigned long long km = __ballot(lane < r && mine >= thr);
+                    const int k = km ? __builtin_ctzll(km) : r;                // probes before the first one that reaches thr
+                    if (k > 0) {
+                        const float upto = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), k - 1));
+                        const int32_t tlast = A.st->clk + 1 + (int32_t)L.s.stm[e + k - 1];
+                        CAFE_SET4(b.c0, b.c1, b.c2, b.c3, f, upto);
+                        CAFE_SET4(b.t0, b.t1, b.t2, b.t3, f, tlast);
+                        if (lane < k) L.s.po[e + lane] = 0;
+                        e += k;
+                        continue;
+                    }
+                }
+                const uint32_t pos = L.s.stm[e];
+                const float c = L.s.pc[e];
+                ctx.pos = pos; ctx.flags = 0;
+                MoveReq mv;
+                int got;
+                if (f >= 0) {
+                    got = lru_hit(b, f, c, thr, ctx, mv);
+                } else {
+                    lru_evict(b, -f - 1, mv);
+                    got = lru_place(b, -f - 1, x, c, thr, ctx);
+                }
+                if (lane == 0) {
+                    L.s.po[e] = (uint8_t)(ctx.flags | (got ? oGot : 0) | (mv.kind ? oEv : 0));
+                    if (mv.kind) {
+                        int p = fast_hash(mv.x, g.fm1) / g.bpp1;
+                        MoveEv mm;
+                        mm.time = 2u * pos + 1u; mm.x = mv.x; mm.cnt = mv.cnt; mm.dic = mv.dic; mm.kind = mv.kind;
+                        mm.pad[0] = p; mm.pad[1] = mm.pad[2] = 0;
+                        uint32_t at = atomicAdd(&A.evcnt[par * g.P1 + p], 1u);
+                        if (at < (uint32_t)g.cap_ev) A.ev[(size_t)par * g.P1 * kCapEv + (size_t)p * kCapEv + at] = mm; else over = 1;
+                        int mi = atomicAdd(n_ev, 1);
+                        if (mi < kCapEvL) mine_ev[mi] = mm; else over = 1;
+                    }
+                }
+                e += 1;
+            }
+            if (lane == 0) store_lru(&stage[s], b, b0 + (int)bl);
+        }
+    }
+    __syncthreads();
     CAFE_STAMP(g.prof, 4);
     if (tid == 0) {
         A.mycnt[q] = (uint32_t)min(*n_ev, kCapEvL);
@@ -1423,7 +1500,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(C
     CAFE_KWIN(3);
     __shared__ __attribute__((aligned(16))) OwnerLds<CAP, false> L;
     __shared__ int heavy[kMaxHeavy];
-    __shared__ int n_heavy, s_total;
+    __shared__ int n_heavy, s_total, n_hv;
     __shared__ float fsum[kMaxSeg];
     // (no look at the control word here: owners only write staging buffers, and k_finish / k_commit refuse a batch whose
     // control word reports a limit -- one memory round trip less in every owner)
@@ -1451,7 +1528,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(C
     }
     b -= nhot;
     if (b < g.P2) {
-        lru_owner<CAP, false>(L, &n_heavy, &s_total, fsum, g, b, 1, LA, sc);
+        lru_owner<CAP, false>(L, heavy, &n_hv, &n_heavy, &s_total, fsum, g, b, 1, LA, sc);
         CAFE_STAMP(0, 6);
         return;
     }
@@ -1501,7 +1578,7 @@ __global__ void __launch_bounds__(kThreads) k_fix(Geo g, MainArgs MA, LruArgs LA
     g.prof = 5;
     __shared__ __attribute__((aligned(16))) OwnerLds<CAP, true> L;
     __shared__ int heavy[kMaxHeavy];
-    __shared__ int n_heavy, s_total;
+    __shared__ int n_heavy, s_total, n_hv;
     __shared__ float fsum[kMaxSeg];
     Ctl *ctl = MA.ctl;
     const int tid = threadIdx.x;
@@ -1531,7 +1608,7 @@ __global__ void __launch_bounds__(kThreads) k_fix(Geo g, MainArgs MA, LruArgs LA
         const int par = round & 1, nxt = par ^ 1;
         for (int p = blockIdx.x * kThreads + tid; p < g.P1; p += gridDim.x * kThreads) LA.evcnt[nxt * g.P1 + p] = 0;
         for (int q = blockIdx.x; q < g.P2; q += gridDim.x) {
-            lru_owner<CAP, true>(L, &n_heavy, &s_total, fsum, g, q, round, LA, sc);
+            lru_owner<CAP, true>(L, heavy, &n_hv, &n_heavy, &s_total, fsum, g, q, round, LA, sc);
             __syncthreads();
         }
         if (!grid_barrier(ctl, gen)) { if (tid == 0) ctl->overflow = 1; return; }
@@ -2057,15 +2134,21 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     const int cap = pick_cap(s, n);
     if (s->ev_chain[0]) (void)hipEventRecord(s->ev_chain[0], st);
     const int grid1 = (!g.hot ? 0 : g.hot_table ? (g.PH + kWaves - 1) / kWaves : g.PH) + g.P2 + g.P1;
+    // The fix-point kernel is persistent (grid barrier between half-rounds): a quiet stream has a few tens of moves per
+    // batch and 64 workgroups suffice; when ids churn (thousands of moves, most partitions in play every round) the
+    // partitions are spread over more workgroups.  All of them are resident: at most two per compute unit of the <2048>
+    // form (40 KB LDS), one of the <8192> form.
+    const uint32_t mv = s->last_moves;
+    const int fix_grid = mv <= 256 ? kFixGrid : (mv <= 2048 || cap == 8192) ? 256 : 512;
     if (cap == 1024) {
         hipLaunchKernelGGL((k_round1<1024>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
-        hipLaunchKernelGGL((k_fix<2048>), dim3(kFixGrid), dim3(kThreads), 0, st, g, MA, LA, sc);
+        hipLaunchKernelGGL((k_fix<2048>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
     } else if (cap == 2048) {
         hipLaunchKernelGGL((k_round1<2048>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
-        hipLaunchKernelGGL((k_fix<2048>), dim3(kFixGrid), dim3(kThreads), 0, st, g, MA, LA, sc);
+        hipLaunchKernelGGL((k_fix<2048>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
     } else {
         hipLaunchKernelGGL((k_round1<8192>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
-        hipLaunchKernelGGL((k_fix<8192>), dim3(kFixGrid), dim3(kThreads), 0, st, g, MA, LA, sc);
+        hipLaunchKernelGGL((k_fix<8192>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
     }
     // ---- finish ----
     const int nb = (n + kScanBlock - 1) / kScanBlock;

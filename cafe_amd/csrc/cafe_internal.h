@@ -85,6 +85,7 @@ struct cafe_sketch {
     uint32_t base_seq = 0;              // snapshots older than this are stale (a reset or a state import came later)
     long long base_real_n = 0;          // real_n after call base_seq
     long long base_clk = 0;             // LRU clock after call base_seq
+    uint32_t last_moves = 0;            // moves (LRU -> main) of the newest call the host has a snapshot of
     int64_t clock_renorms = 0;          // times the LRU timestamps were rewritten to ranks (k_clock_renorm)
     int opt_fuse_fields = 1, opt_verify = 1;
     struct Issued { uint32_t seq; int n; };

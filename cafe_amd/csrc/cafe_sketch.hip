@@ -706,6 +706,7 @@ static void read_mirror(cafe_sketch *s, Mirror *out) {
 static void take_snapshot(cafe_sketch *s, const Mirror &m) {
     s->base_real_n = m.st.real_n;
     s->base_clk = m.st.clk;
+    s->last_moves = m.moves;
     s->base_seq = m.seq;
     s->fifo_hint = m.st.fifo_len;
     if (s->thr_dirty_seq && (int32_t)(m.seq - s->thr_dirty_seq) >= 0) {
