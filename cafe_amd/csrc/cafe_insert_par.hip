@@ -885,7 +885,19 @@ __device__ inline void hot_table_owner(float *acc /* [kHotKeys] */, float *runs 
 // are in batch order, or sorted by (slot, time): either way the last match is the latest.  (A handful of moves per batch
 // look here.)
 __device__ inline float hot_cnt_at(const unsigned long long *__restrict__ hk, const float *__restrict__ hr, int nh,
-                                   uint32_t key, uint32_t time, float base) {
+                                   uint32_t key, uint32_t time, float base, bool sorted) {
+    if (sorted) {
+        // keys ascend by (slot, time): the last entry below (slot, time) is the latest one in front of the move, if it
+        // is an entry of this slot at all.  (Thousands of moves per batch look here when the id stream churns.)
+        const unsigned long long bound = ((unsigned long long)key << 39) | ((unsigned long long)time << 16);
+        int lo = 0, hi = nh;                    // first index with hk >= bound
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (hk[mid] < bound) lo = mid + 1; else hi = mid;
+        }
+        if (lo == 0) return base;
+        return (uint32_t)(hk[lo - 1] >> 39) == key ? hr[lo - 1] : base;
+    }
     float best = base;
     for (int j = 0; j < nh; ++j) {
         const unsigned long long k = hk[j];
@@ -902,10 +914,11 @@ __device__ inline void patch_hot(MainR &b, const Geo &g, const uint32_t *__restr
     const int nh = (int)(off[off_hot0(g) + ph + 1] - oh0);
     if (nh <= 0) return;
     const uint32_t kb = (uint32_t)(h1 - ph * g.bpph) << 2;
-    if (b.d0) b.c0 = hot_cnt_at(hkey + oh0, hrun + oh0, nh, kb | 0u, time, b.c0);
-    if (b.d1) b.c1 = hot_cnt_at(hkey + oh0, hrun + oh0, nh, kb | 1u, time, b.c1);
-    if (b.d2) b.c2 = hot_cnt_at(hkey + oh0, hrun + oh0, nh, kb | 2u, time, b.c2);
-    if (b.d3) b.c3 = hot_cnt_at(hkey + oh0, hrun + oh0, nh, kb | 3u, time, b.c3);
+    const bool sorted = !g.hot_table;           // the sorting owner leaves (slot, time) order, the table owner batch order
+    if (b.d0) b.c0 = hot_cnt_at(hkey + oh0, hrun + oh0, nh, kb | 0u, time, b.c0, sorted);
+    if (b.d1) b.c1 = hot_cnt_at(hkey + oh0, hrun + oh0, nh, kb | 1u, time, b.c1, sorted);
+    if (b.d2) b.c2 = hot_cnt_at(hkey + oh0, hrun + oh0, nh, kb | 2u, time, b.c2, sorted);
+    if (b.d3) b.c3 = hot_cnt_at(hkey + oh0, hrun + oh0, nh, kb | 3u, time, b.c3, sorted);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1212,11 +1225,17 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
                     CAFE_SET4(b.d0, b.d1, b.d2, b.d3, hit, dic);
                     e += r;
                 } else if (!(time0 & 1u)) {
-                    if (lane == 0) {
-                        if (L.s.po[e] == 0) { changed = 1; if (MOVES) A.ldirty[par * g.P2 + fast_hash(x0, g.fm2) / g.bpp2] = 1; }
-                        L.s.po[e] = oMiss;
+                    // a run of probes of an id that is not in the bucket (a frequent id that still lives in the LRU
+                    // table): all misses, no change to the bucket, 64 items at a time
+                    const int idx = e + lane;
+                    const bool same = idx < total && L.s.sg[idx] == bl && !(L.s.stm[idx] & 1u) && L.s.px[idx] == x0;
+                    const unsigned long long m = __ballot(same);
+                    const int r = (~m) ? __builtin_ctzll(~m) : 64;            // length of the run starting at e (>= 1)
+                    if (lane < r) {
+                        if (L.s.po[idx] == 0) { changed = 1; if (MOVES) A.ldirty[par * g.P2 + fast_hash(x0, g.fm2) / g.bpp2] = 1; }
+                        L.s.po[idx] = oMiss;
                     }
-                    e += 1;
+                    e += r;
                 } else {
                     if (MOVES) {
                         ctx.pushed = 0;
@@ -1591,17 +1610,25 @@ __global__ void __launch_bounds__(kThreads) k_fix(Geo g, MainArgs MA, LruArgs LA
     uint32_t gen = 0;
     for (int round = 2; round <= g.max_rounds; ++round) {
         const int prev = (round & 1) ^ 1;
+        const int pslot = round == 2 ? 6 : 7;       // diagnostic builds: rounds 2 and 3 (and later, overwriting) are stamped
+        unsigned long long ran = 0;
+        (void)pslot; (void)ran;
+        CAFE_STAMP(pslot, 0);
         for (int p = blockIdx.x; p < g.P1; p += gridDim.x) {
             // partitions that have moves now, or ran with moves before (they may have to run without)
             const uint32_t need = tid == 0 ? (MA.evcnt[prev * g.P1 + p] | MA.prevcnt[p]) : 0u;
             if (!__syncthreads_or(need != 0)) continue;
             main_owner<CAP, true, true>(L, heavy, &n_heavy, fsum, g, p, round, MA, sc);
             __syncthreads();
+            ran += 1;
         }
+        CAFE_STAMP(pslot, 1);
         if (!grid_barrier(ctl, gen)) { if (tid == 0) ctl->overflow = 1; return; }
+        CAFE_STAMP(pslot, 2);
         if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         if (!__hip_atomic_load(&ctl->changed[round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
             if (blockIdx.x == 0 && tid == 0) ctl->final_round = (uint32_t)round;
+            CAFE_STAMP_VAL(pslot, 5, ran);
             return;
         }
         if (round == g.max_rounds) return;         // not settled
@@ -1610,8 +1637,12 @@ __global__ void __launch_bounds__(kThreads) k_fix(Geo g, MainArgs MA, LruArgs LA
         for (int q = blockIdx.x; q < g.P2; q += gridDim.x) {
             lru_owner<CAP, true>(L, heavy, &n_hv, &n_heavy, &s_total, fsum, g, q, round, LA, sc);
             __syncthreads();
+            ran += 1ull << 16;
         }
+        CAFE_STAMP(pslot, 3);
         if (!grid_barrier(ctl, gen)) { if (tid == 0) ctl->overflow = 1; return; }
+        CAFE_STAMP(pslot, 4);
+        CAFE_STAMP_VAL(pslot, 5, ran);
         if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     }
 }
@@ -2139,7 +2170,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     // partitions are spread over more workgroups.  All of them are resident: at most two per compute unit of the <2048>
     // form (40 KB LDS), one of the <8192> form.
     const uint32_t mv = s->last_moves;
-    const int fix_grid = mv <= 256 ? kFixGrid : (mv <= 2048 || cap == 8192) ? 256 : 512;
+    const int fix_grid = mv <= 256 ? kFixGrid : cap == 8192 ? 256 : 512;
     if (cap == 1024) {
         hipLaunchKernelGGL((k_round1<1024>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
         hipLaunchKernelGGL((k_fix<2048>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
