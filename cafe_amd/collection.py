@@ -21,7 +21,7 @@ from .sketch import HotSketch, _ptr, _stream
 
 class CafeEmbeddingCollection:
     def __init__(self, counts, dim, hotn, hash_sizes, offsets=None, threshold=500, adjust_thres=1, alpha=1.0000005,
-                 device=None, seed=0, lru_first=1):
+                 device=None, seed=0, lru_first=1, init_on_device=False):
         if not torch.cuda.is_available():
             raise _lib.CafeError("cafe_amd needs a GPU: there is no CPU path in this package")
         self.L = _lib.load()
@@ -43,10 +43,17 @@ class CafeEmbeddingCollection:
         self._cold = torch.empty(total, self.dim, device=self.device)
         self.weight_hash = []
         r0 = 0
+        gd = None
+        if init_on_device:          # tens of GB of tables (cfg4): draw on the GPU instead of through host memory
+            gd = torch.Generator(device=self.device)
+            gd.manual_seed(seed)
         for n, h in zip(self.counts, self.hash_sizes):
             w = self._cold[r0:r0 + h]
             b = float(np.sqrt(1.0 / n))
-            w.copy_((torch.rand(h, self.dim, generator=g) * 2 - 1) * b)
+            if gd is not None:
+                w.uniform_(-b, b, generator=gd)
+            else:
+                w.copy_((torch.rand(h, self.dim, generator=g) * 2 - 1) * b)
             self.weight_hash.append(w)
             r0 += h
         self._make_tables()
