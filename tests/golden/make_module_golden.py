@@ -39,7 +39,13 @@ SPECS = {
     # D=128 rows, larger threshold: many LRU hits before a promotion
     "module_dim128": dict(seed=13, counts=[900, 20000], hash_sizes=[7, 61], dim=128, hotn=100, thr=5, batch=64, steps=8,
                           lr=0.05, a=1.3),
+    # the 26 Criteo-Kaggle fields at BASELINE.json configs[1]'s sizes (compress 0.001, hash-rate 0.3, D = 16): hotn and the
+    # per-field hash sizes as dlrm_s_pytorch.py:1237-1242 and :320 compute them; field cardinalities from 3 to 10 M
+    "module_kaggle26": dict(seed=14, counts="kaggle", hash_sizes="kaggle", dim=16, hotn="kaggle", thr=3, batch=64, steps=5,
+                            lr=0.1, a=1.1),
 }
+KAGGLE_COUNTS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306, 10,
+                 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]          # the reference's Kaggle count file (cfg2)
 
 
 def worker(name, spec, out_path):
@@ -51,6 +57,11 @@ def worker(name, spec, out_path):
     torch.set_num_threads(1)
     rng = np.random.default_rng(spec["seed"])
     counts, hs, D, hotn, B = spec["counts"], spec["hash_sizes"], spec["dim"], spec["hotn"], spec["batch"]
+    if counts == "kaggle":
+        counts = list(KAGGLE_COUNTS)
+        cr, hr = 0.001, 0.3
+        hotn = int(sum(counts) * cr * (1 - hr) * (D * 4 / (D * 4 + 48)))        # dlrm_s_pytorch.py:1237-1240
+        hs = [int(round(cr * hr * n + 0.51)) for n in counts]                    # dlrm_s_pytorch.py:1241, :320
     F = len(counts)
     offs = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "sklib.so"))
@@ -114,7 +125,10 @@ def lib_query(lib, gids):
 
 def main():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL)
+    only = sys.argv[1:]
     for name, spec in SPECS.items():
+        if only and name not in only:
+            continue
         out = os.path.join(HERE, name + ".npz")
         env = dict(os.environ, MALLOC_PERTURB_="165")
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--worker", name, json.dumps(spec), out], env=env,
