@@ -212,6 +212,8 @@ def main():
                 t[0].clamp_(min=1)
         eng.forward(ids_dev[i % nb], out=out)
         eng.backward_update(grad, args.lr, per_field_calls=cadence)
+        if world > 1 and not (args.drift and (i + 1) % nb == 0):
+            eng.prefetch(ids_dev[(i + 1) % nb])       # the next batch's ids are known: route them one step ahead
 
     it = 0
     for _ in range(args.preheat + args.warmup):
@@ -340,6 +342,7 @@ def main():
                                         {True: "one per field (reference cadence), run as one insert per step",
                                          "loop": "one per field, issued one by one", False: "one per step"}[cadence]),
                        "parallelism": "single GPU" if world == 1 else f"id-hash sharded x{world}, RCCL all-to-all",
+                       "host_syncs_in_step": getattr(eng, "host_syncs_in_step", 0),
                        "preheat_steps": args.preheat, "id_batches": nb, "drift": args.drift, "repetitions": reps,
                        "cadence_miss": (eng.sketch.counters()["cadence_miss"] if getattr(eng, "sketch", None) else None)},
             "window_ms": {"median": round(dt * 1e3, 4), "min": round(windows[0] * 1e3, 4), "max": round(windows[-1] * 1e3, 4),

@@ -61,6 +61,7 @@ SYMBOLS = {
     "cafe_forward_gid_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "cafe_migrate_gid_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp]),
     "cafe_backward_sgd_gid_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_float, _vp]),
+    "cafe_backward_sgd_gid_strided_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp]),
     "cafe_grad_norm_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
 }
 

@@ -726,7 +726,7 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                                                       const int32_t *__restrict__ fields, const float *__restrict__ grad,
                                                       float *__restrict__ w_hot, float *const *__restrict__ w_cold,
                                                       const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr,
-                                                      const int32_t *__restrict__ skip_if_2) {
+                                                      const int32_t *__restrict__ skip_if_2, int gstride) {
     CAFE_KWIN(6);
     __shared__ __attribute__((aligned(16))) unsigned long long key[kBwdCap];
     __shared__ float4 bpart[2][VPL][256];      // border partial sums: [0] head of a group's range, [1] tail
@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                 const bool live = begin + e < end;
                 const unsigned long long ke = key[min(begin + e, n - 1)];
                 const uint32_t i = (uint32_t)ke, k = (uint32_t)(ke >> 32);
-                const float4 *g = reinterpret_cast<const float4 *>(grad + (size_t)i * dim);
+                const float4 *g = reinterpret_cast<const float4 *>(grad + (size_t)i * gstride);
                 bool last = false;
                 unsigned m = 0;
                 if (live) {
@@ -896,7 +896,7 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
 // rows in, table rows updated) on `st`, ordered behind t->ev_plan (recorded here on pst) when the streams differ.
 static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,
                            int batch, int total, float lr, hipStream_t st, hipStream_t pst, int part = 3,
-                           const int32_t *skip_if_2 = nullptr) {
+                           const int32_t *skip_if_2 = nullptr, int gstride = 0) {
     if (total <= 0) return 0;
     const int64_t rows = (int64_t)t->hotn + t->total_cold_rows;
     if (rows >= (int64_t)0xFFFFFFFFLL) { set_error("cafe_backward_sgd_dev: more than 2^32 table rows"); return 1; }
@@ -932,7 +932,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     const int grid = max_tiles;
 #define CAFE_SEG(L, V)                                                                                                   \
     hipLaunchKernelGGL((k_bwd_segments<L, V>), dim3(grid), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
-                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_if_2)
+                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_if_2, gstride ? gstride : t->dim)
     const int tk = 1;
     if (t->timing) (void)hipEventRecord(t->ev_t[tk][0], st);
     if (vpl == 1) {
@@ -966,6 +966,19 @@ extern "C" int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, co
 extern "C" int cafe_backward_sgd_gid_dev(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que,
                                          const float *d_grad_out, int n, float lr, cafe_stream_t stream) {
     return backward_common(t, d_fields, d_que, d_grad_out, 1, n, lr, (hipStream_t)stream, (hipStream_t)stream);
+}
+
+// the same with gradient rows `grad_row_stride` floats apart (a multiple of 4, >= dim): the rows of a packed exchange
+// buffer [n][dim + 4] that carries a lookup's score behind its gradient row (one all-to-all instead of two)
+extern "C" int cafe_backward_sgd_gid_strided_dev(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que,
+                                                 const float *d_grad_out, int grad_row_stride, int n, float lr,
+                                                 cafe_stream_t stream) {
+    if (grad_row_stride < t->dim || (grad_row_stride & 3)) {
+        set_error("cafe_backward_sgd_gid_strided_dev: row stride %d must be a multiple of 4 and at least dim = %d", grad_row_stride, t->dim);
+        return 1;
+    }
+    return backward_common(t, d_fields, d_que, d_grad_out, 1, n, lr, (hipStream_t)stream, (hipStream_t)stream, 3, nullptr,
+                           grad_row_stride);
 }
 
 // scores -> batch_insert_val -> migration -> backward + SGD, in the reference's order (dlrm_s_pytorch.py:1642-1658),

@@ -2064,7 +2064,11 @@ static int pick_cap(cafe_sketch *s, int n) {
     if (s->force_cap_once) return s->force_cap_once;
     if (s->force_cap) return s->force_cap;
     const Mirror *m = reinterpret_cast<const Mirror *>(s->h_pinned);
-    if (s->last_seen_batch != n || m->seq == 0) { s->last_seen_batch = n; return 2048; }
+    // a batch size far from the one the snapshot's partition sizes belong to (or no snapshot yet): the largest owners,
+    // which take any partition up to 8192 items; sizes that wander by a few percent (a shard's share of a step) keep
+    // using the snapshot, whose margin below covers them
+    const long ref_n = s->last_seen_batch;
+    if (m->seq == 0 || (long)n * 4 > ref_n * 5 || (long)n * 4 < ref_n * 3) { s->last_seen_batch = n; return 8192; }
     const long big = std::max(m->st.maxpart, s->opt_hot_table ? 0 : m->st.pad[3]);       // (hot partitions of the table form have no limit)
     if (m->st.fallback) return 8192;
     if (big + big / 8 + 32 <= 1024) return 1024;

@@ -6,17 +6,26 @@ The reference is single-device; this is the MI355X-native scale-
     * hotn / G hot rows,
     * for every field ceil(hash_size_f / G) cold rows, addressed gid mod that size,
 so a shard is, by itself, exactly the single-GPU layer fed the sub-stream of lookups routed to it (in source
-rank order, then original order) -- which is how parity is defined and tested per shard.
+rank order, then original order) with ONE batch_insert_val per step -- which is how parity is defined and tested
+per shard.
 
 Per step (data-parallel batch, B samples per rank):
-    forward   all_to_all(ids) -> owners run the fused query+gather -> all_to_all(rows) back
-    backward  per-field sum of gradient norms all-reduced (scores are normalised over the GLOBAL batch)
-              -> all_to_all(gradient rows, scores) -> owners run insert / migration / backward+SGD
+    route     owner of every lookup, stable order by owner, counts exchanged, ids exchanged.  It depends on the ids
+              only, so `prefetch(next_ids)` runs it one step ahead on the exchange stream: the split sizes (which
+              torch.distributed wants on the host) are then read from a transfer that finished long ago, and the step
+              itself never waits for the host.
+    forward   owners run the fused query+gather -> all_to_all(rows) back
+    backward  per-field sums of gradient norms all-reduced (scores are normalised over the GLOBAL batch)
+              -> ONE all_to_all of rows [gradient row | score | 3 pad floats] -> owners run insert / migration /
+              backward+SGD straight from the received buffer (strided rows)
 All-to-all is the collective that fits xGMI: every pair of GPUs has its own link, so the G-1 transfers of a rank
-run concurrently (ring all-reduce would be bound by one link).
+run concurrently (a ring all-reduce would be bound by one link).  The collectives run on a stream of their own,
+ordered against the compute stream by events; forward_async() hands back a handle so that the caller's bottom MLP
+runs on the compute stream while the rows travel.
 
 The exchange logic below is plain torch + torch.distributed and also runs on CPU tensors over gloo (tests);
 the owner-side compute is a backend object: HipShardBackend (libcafe_hip.so) in production."""
+import contextlib
 import ctypes
 
 import numpy as np
@@ -26,6 +35,7 @@ import torch.distributed as dist
 from . import _lib
 
 _MIX = 2654435761
+PAD = 4          # floats behind a gradient row in the packed exchange buffer: [score, 0, 0, 0] keeps rows 16-byte aligned
 
 
 def owner_of(gids, world):
@@ -74,16 +84,36 @@ class HipShardBackend:
                    "cafe_grad_norm_dev")
         return gn, sums
 
-    def backward_gid(self, gids, fields, que, grads, scores, lr):
+    def backward_gid(self, gids, fields, que, packed, lr):
+        """packed: [n, dim + PAD] float32, a lookup's gradient row with its score at column dim."""
         n = gids.numel()
         ins = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        scores = packed[:, self.dim].contiguous()
         st = self._st()
         _lib.check(self.L.cafe_insert_dev(self.sketch.h, self._p(gids), self._p(scores), n, self._p(ins), st), "cafe_insert_dev")
         _lib.check(self.L.cafe_migrate_gid_dev(self.sketch.h, self.coll.tables, self._p(gids), self._p(fields), self._p(ins),
                                                n, st), "cafe_migrate_gid_dev")
-        _lib.check(self.L.cafe_backward_sgd_gid_dev(self.coll.tables, self._p(fields), self._p(que), self._p(grads), n,
-                                                    ctypes.c_float(lr), st), "cafe_backward_sgd_gid_dev")
+        _lib.check(self.L.cafe_backward_sgd_gid_strided_dev(self.coll.tables, self._p(fields), self._p(que), self._p(packed),
+                                                            packed.shape[1], n, ctypes.c_float(lr), st),
+                   "cafe_backward_sgd_gid_strided_dev")
         return ins[:n]
+
+
+class _Route:
+    """Where the lookups of one batch go: computed from the ids alone (possibly one step ahead)."""
+    __slots__ = ("ids", "B", "order", "ss", "rs", "r_gids", "r_fields", "ready")
+
+
+class _Pending:
+    """Handle of forward_async(): wait() orders the compute stream behind the returning rows and hands back `out`."""
+
+    def __init__(self, out, event):
+        self.out, self.event = out, event
+
+    def wait(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+        return self.out
 
 
 class ShardedCafeEmbedding:
@@ -108,6 +138,24 @@ class ShardedCafeEmbedding:
         self.sketch = getattr(backend, "sketch", None)
         self.offsets = torch.from_numpy(self.offsets_np).to(self.device)
         self._fields = None
+        self._route = None
+        self.last_received = 0
+        self.host_syncs_in_step = 0        # times a step had to wait for split sizes (0 when every batch was prefetched)
+        # collectives on a stream of their own (device tensors only; CPU tensors over gloo run inline)
+        self._xs = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    # -- streams ---------------------------------------------------------------------------------
+    def _on_exchange_stream(self):
+        """Context: work is queued on the exchange stream, behind everything queued on the compute stream so far."""
+        if self._xs is None:
+            return contextlib.nullcontext()
+        self._xs.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self._xs)
+
+    def _join(self):
+        """The compute stream continues behind the exchange stream's work."""
+        if self._xs is not None:
+            torch.cuda.current_stream().wait_stream(self._xs)
 
     # -- exchange helpers ------------------------------------------------------------------------
     def _a2a(self, send, send_splits, recv_splits):
@@ -124,8 +172,9 @@ class ShardedCafeEmbedding:
                                input_split_sizes=list(send_splits), group=self.group)
         return out
 
-    def forward(self, local_ids, out=None):
-        """local_ids [F, B] int64 (this rank's samples).  Returns [F, B, D]."""
+    def _make_route(self, local_ids):
+        """Owner of every lookup, the counts and the ids exchanged; everything is queued on the current stream except
+        the read of the split sizes, which torch.distributed needs on the host."""
         F, B = local_ids.shape
         n = F * B
         if self._fields is None or self._fields.numel() != n:
@@ -138,33 +187,81 @@ class ShardedCafeEmbedding:
             send_counts = send_counts.cpu()
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
-        ss, rs = send_counts.tolist(), recv_counts.tolist()                          # split sizes live on the host
+        r = _Route()
+        r.ids, r.B, r.order = local_ids, B, order
+        if send_counts.is_cuda:
+            # both count vectors to pinned host memory without blocking; read at first use (ready.synchronize())
+            hs = torch.empty(2, self.world, dtype=send_counts.dtype, pin_memory=True)
+            hs[0].copy_(send_counts, non_blocking=True); hs[1].copy_(recv_counts, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
+            ev.synchronize()               # (on the exchange stream when prefetched: the compute stream is not involved)
+            r.ss, r.rs = hs[0].tolist(), hs[1].tolist()
+        else:
+            r.ss, r.rs = send_counts.tolist(), recv_counts.tolist()
         packed = (self._fields[order].to(torch.int64) << 32) | (gids[order].to(torch.int64) & 0xFFFFFFFF)
-        got = self._a2a(packed, ss, rs)
-        r_gids = (got & 0xFFFFFFFF).to(torch.int32)          # wraps to the int32 bit pattern
-        r_fields = (got >> 32).to(torch.int32)
-        self.last_received = int(r_gids.numel())
-        que, rows = self.backend.forward_gid(r_gids, r_fields)
-        back = self._a2a(rows, rs, ss)
+        got = self._a2a(packed, r.ss, r.rs)
+        r.r_gids = (got & 0xFFFFFFFF).to(torch.int32)          # wraps to the int32 bit pattern
+        r.r_fields = (got >> 32).to(torch.int32)
+        r.ready = None
+        if self._xs is not None:
+            r.ready = torch.cuda.Event(); r.ready.record()
+        return r
+
+    def prefetch(self, local_ids):
+        """Route the NEXT batch now, on the exchange stream (the ids of a training step are known before the step): the
+        later forward(local_ids) of the same tensor then starts without any host synchronisation."""
+        with self._on_exchange_stream():
+            self._route = self._make_route(local_ids)
+
+    # -- the step ----------------------------------------------------------------------------------
+    def forward_async(self, local_ids, out=None):
+        """local_ids [F, B] int64 (this rank's samples).  Returns a handle; handle.wait() -> [F, B, D]."""
+        F, B = local_ids.shape
+        n = F * B
+        r = self._route
+        if r is None or r.ids is not local_ids:
+            self.host_syncs_in_step += 1
+            r = self._make_route(local_ids)
+        elif r.ready is not None:
+            torch.cuda.current_stream().wait_event(r.ready)
+        self._route = None
+        self.last_received = int(r.r_gids.numel())
+        que, rows = self.backend.forward_gid(r.r_gids, r.r_fields)
         if out is None:
             out = torch.empty(F, B, self.dim, device=self.device)
-        out.view(n, self.dim)[order] = back
-        self._saved = (B, order, ss, rs, r_gids, r_fields, que)
-        return out
+        with self._on_exchange_stream():
+            back = self._a2a(rows, r.rs, r.ss)
+            out.view(n, self.dim)[r.order] = back
+            ev = None
+            if self._xs is not None:
+                ev = torch.cuda.Event(); ev.record()
+                for t in (rows, back, out):
+                    t.record_stream(self._xs)
+        self._saved = (B, r.order, r.ss, r.rs, r.r_gids, r.r_fields, que)
+        return _Pending(out, ev)
+
+    def forward(self, local_ids, out=None):
+        return self.forward_async(local_ids, out).wait()
 
     def backward_update(self, grad_out, lr, per_field_calls=False):
-        """grad_out [F, B, D].  Scores are normalised per field over the global batch (all ranks)."""
+        """grad_out [F, B, D].  Scores are normalised per field over the global batch (all ranks); every shard's sketch
+        sees ONE batch_insert_val per step over the lookups routed to it."""
         B, order, ss, rs, r_gids, r_fields, que = self._saved
-        F = self.F
+        F, D = self.F, self.dim
         n = F * B
         grad_out = grad_out.contiguous()
         gn, sums = self.backend.grad_norm(grad_out, B)
-        dist.all_reduce(sums, group=self.group)
-        scores = gn.view(F, B) * float(B * self.world) / sums[:, None]              # sk_embedding_bag.py:189, global batch
-        g_send = grad_out.view(n, self.dim)[order]
-        s_send = scores.reshape(-1)[order]
-        r_grads = self._a2a(g_send, ss, rs)
-        r_scores = self._a2a(s_send, ss, rs)
-        ins = self.backend.backward_gid(r_gids, r_fields, que, r_grads, r_scores, lr)
-        self._last = (r_gids, r_fields, r_scores, ins)
+        with self._on_exchange_stream():
+            dist.all_reduce(sums, group=self.group)
+            scores = gn.view(F, B) * float(B * self.world) / sums[:, None]          # sk_embedding_bag.py:189, global batch
+            send = torch.zeros(n, D + PAD, device=self.device)
+            send[:, :D] = grad_out.view(n, D)[order]
+            send[:, D] = scores.reshape(-1)[order]
+            packed = self._a2a(send, ss, rs)
+            if self._xs is not None:
+                for t in (grad_out, gn, sums, scores, send, packed):
+                    t.record_stream(self._xs)
+        self._join()
+        ins = self.backend.backward_gid(r_gids, r_fields, que, packed, lr)
+        self._last = (r_gids, r_fields, packed[:, D], ins)
         return scores.reshape(-1), ins

@@ -202,6 +202,11 @@ int cafe_migrate_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const int32_t *d_gi
                          const int32_t *d_ins, int n, cafe_stream_t stream);
 int cafe_backward_sgd_gid_dev(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,
                               int n, float lr, cafe_stream_t stream);
+/* The same with gradient rows grad_row_stride floats apart (a multiple of 4, >= dim): the multi-GPU path sends a
+ * lookup's gradient row and its score in ONE all-to-all, as rows of dim + 4 floats with the score at column dim
+ * (cafe_amd/sharded.py), and the owner updates straight from that buffer. */
+int cafe_backward_sgd_gid_strided_dev(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que,
+                                      const float *d_grad_out, int grad_row_stride, int n, float lr, cafe_stream_t stream);
 /* First half of cafe_scores_dev: d_norms[f*batch+i] = ||g_i||, d_field_sums[f] = sum_i ||g_i|| (fixed order), so that
  * ranks can all-reduce the sums before scaling (sk_embedding_bag.py:178-189 over the global batch). */
 int cafe_grad_norm_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_norms, float *d_field_sums,

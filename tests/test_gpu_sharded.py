@@ -50,7 +50,9 @@ def test_gid_entry_points_match_oracle(dim, oracle_mod):
         _close(rows.cpu().numpy(), want_rows.numpy(), f"step {step} rows")
         grads = torch.randn(n, dim, device=dev, generator=torch.Generator(device=dev).manual_seed(step))
         scores = (torch.rand(n, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + step)) * 2).contiguous()
-        ins = hip.backward_gid(t_g, t_f, que, grads, scores, lr)
+        packed = torch.zeros(n, dim + 4, device=dev)            # the exchange buffer's rows: [gradient row | score | pad]
+        packed[:, :dim] = grads; packed[:, dim] = scores
+        ins = hip.backward_gid(t_g, t_f, que, packed, lr)
         # the CPU double applies SGD lookup by lookup in float32; sum per row in float64 here for a tighter reference
         g64 = grads.cpu().numpy().astype(np.float64)
         want_ins = cpu.sk.insert_val(gids, scores.cpu().numpy())
@@ -92,10 +94,13 @@ def _rank(rank, world, port, q):
         eng = ShardedCafeEmbedding(counts, dim, hotn, hash_sizes, offsets, threshold=thr, seed=1)
         ref = om.Oracle(lh, thr, 1, 1.0000005, 1)
         rng = np.random.default_rng(5 + rank)
+        batches = []
         for step in range(8):
             ids = np.stack([(rng.zipf(1.2, size=B) - 1) % c for c in counts]).astype(np.int64)
             ids[0] = np.maximum(ids[0], 1)
-            out = eng.forward(torch.from_numpy(ids).cuda())
+            batches.append(torch.from_numpy(ids).cuda())
+        for step in range(8):
+            out = eng.forward(batches[step])
             assert out.shape == (F, B, dim) and bool(torch.isfinite(out).all())
             grad = torch.randn(F, B, dim, device="cuda", generator=torch.Generator(device="cuda").manual_seed(10 * step + rank))
             scores, ins = eng.backward_update(grad, lr)
@@ -104,6 +109,9 @@ def _rank(rank, world, port, q):
             assert np.array_equal(r_ins.cpu().numpy(), want), f"step {step}: per-shard ins"
             own = owner_of(r_gids, world)
             assert bool((own == rank).all()), "a lookup reached a rank that does not own it"
+            if step % 2 == 0 and step + 1 < 8:
+                eng.prefetch(batches[step + 1])       # routed one step ahead on the exchange stream
+        assert eng.host_syncs_in_step == 4
         bad = om.states_equal(eng.sketch.state(), ref.state())
         assert not bad, bad
         q.put((rank, "ok"))

@@ -1,4 +1,4 @@
-"""Multi-rank path of cafe_amd.sharded.ShardedCafeEmbedding on CPU: world_size 2 over gloo, with the CPU
+"""Multi-rank path of cafe_amd.sharded.ShardedCafeEmbedding on CPU: world_size 2 and 4 over gloo, with the CPU
 oracle standing in for the owner-side HIP calls (parity at G > 1 is defined per shard --
 shard g must equal an independent sketch fed the sub-stream of lookups routed to g, in source-rank then
 batch order).  What is tested here is the exchange: routing by owner, the two all-to-alls and their inverse
@@ -44,7 +44,9 @@ class OracleShardBackend:
         gn = torch.sqrt((grad * grad).sum(-1)).reshape(-1)
         return gn, gn.view(grad.shape[0], batch).sum(1)
 
-    def backward_gid(self, gids, fields, que, grads, scores, lr):
+    def backward_gid(self, gids, fields, que, packed, lr):
+        grads, scores = packed[:, :self.dim], packed[:, self.dim].contiguous()      # [gradient row | score | pad]
+        assert packed.shape[1] == self.dim + 4 and float(packed[:, self.dim + 1:].abs().sum()) == 0.0
         g, f, q = gids.numpy(), fields.numpy(), que.numpy()
         self.stream.append((g.copy(), scores.numpy().copy()))
         ins = self.sk.insert_val(g, scores.numpy())
@@ -78,11 +80,18 @@ def _worker(rank, world, port, q):
         # an independent sketch per shard, fed what the parity definition says the shard must see
         ref = om.Oracle(lh, thr, 1, 1.0000005, 1)
         rng = np.random.default_rng(5 + rank)
+        nxt = None
         for step in range(6):
-            ids = np.stack([(rng.zipf(1.2, size=B) - 1) % c for c in counts]).astype(np.int64)
-            ids[0] = np.maximum(ids[0], 1)
-            t_ids = torch.from_numpy(ids)
-            out = eng.forward(t_ids)
+            if nxt is None:
+                ids = np.stack([(rng.zipf(1.2, size=B) - 1) % c for c in counts]).astype(np.int64)
+                ids[0] = np.maximum(ids[0], 1)
+                t_ids = torch.from_numpy(ids)
+            else:
+                ids, t_ids = nxt
+            if step % 2 == 0:       # every other batch is routed one step ahead (prefetch), the others inside forward
+                out = eng.forward(t_ids)
+            else:
+                out = eng.forward_async(t_ids).wait()
             # every rank learns everybody's ids, gradients and tables to check the exchange end to end
             all_ids = [torch.empty_like(t_ids) for _ in range(world)]
             dist.all_gather(all_ids, t_ids)
@@ -117,6 +126,12 @@ def _worker(rank, world, port, q):
                     row = w_hot_o[-qq[k]] if qq[k] < 0 else w_cold_o[f][qq[k] % lhs[f]]
                     assert np.array_equal(outv[i], row), f"step {step}: row of lookup {i} (owner {o})"
             scores, ins = eng.backward_update(grad, lr)
+            nxt = None
+            if step % 2 == 0:
+                ids2 = np.stack([(rng.zipf(1.2, size=B) - 1) % c for c in counts]).astype(np.int64)
+                ids2[0] = np.maximum(ids2[0], 1)
+                nxt = (ids2, torch.from_numpy(ids2))
+                eng.prefetch(nxt[1])
             # (3) scores are normalised over the global batch
             all_g = [torch.empty_like(grad) for _ in range(world)]
             dist.all_gather(all_g, grad)
@@ -129,6 +144,9 @@ def _worker(rank, world, port, q):
             want_ins = ref.insert_val(sub_g, sub_s)
             assert np.array_equal(ins.numpy(), want_ins), "per-shard ins"
         assert not om.states_equal(be.sk.state(), ref.state())
+        assert eng.host_syncs_in_step == 3          # the three batches that were not prefetched
+        # one batch_insert_val per step and shard: the shard's call counter advanced once per step (decay, reset test)
+        assert be.sk.state()["batch_num"] == 6
         q.put((rank, "ok"))
     except Exception as e:            # surface the failure in the parent
         import traceback
@@ -145,8 +163,8 @@ def _free_port():
     return p
 
 
-def test_sharded_exchange_world2():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_exchange(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
