@@ -46,3 +46,42 @@ def test_bad_files_are_rejected(tmp_path):
         f.write(b"\\0\\0")
     with pytest.raises(ValueError):
         cd.BinaryCTRDataset(num_fields=3, **paths)
+
+
+def test_batches_equal_the_reference_loader(tmp_path):
+    """tests/golden/loader_kaggle.npz: what the reference's own KaggleDataset + DataLoader(collate_wrapper_criteo_offset2)
+    (dlrm_data_pytorch.py:315-392, :409-421, :655-690) yield for a tiny file set, recorded by
+    tests/golden/make_loader_golden.py.  The reference's 'train' split of a small file is the whole file (its split
+    point is the hard-coded Kaggle row count, :342); here the split is at 6/7 of the rows, so the reference's batches
+    0..5 are this loader's train split and its batch 6 is the test split.  train_len = S reproduces the reference's
+    split literally."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "loader_kaggle.npz"))
+    B, nb = int(g["batch"]), int(g["num_batches"])
+    paths = {"cat_path": str(tmp_path / "sparse.bin"), "label_path": str(tmp_path / "label.bin"),
+             "count_path": str(tmp_path / "count.bin"), "dense_path": str(tmp_path / "dense.bin")}
+    g["cat"].tofile(paths["cat_path"]); g["label"].tofile(paths["label_path"])
+    g["count_file"].tofile(paths["count_path"]); g["dense"].tofile(paths["dense_path"])
+    S = len(g["label"])
+    assert S * 6 // 7 == 6 * B and nb == 7
+
+    def check(batch, k):
+        x, ids, y = batch
+        assert x.dtype == torch.float32 and np.array_equal(x.numpy(), g[f"X_{k}"])              # X_int
+        assert ids.dtype == torch.int64 and np.array_equal(ids.numpy(), g[f"lS_i_{k}"])         # torch.stack(lS_i): [26, B]
+        assert y.dtype == torch.float32 and np.array_equal(y.numpy(), g[f"T_{k}"])              # [B, 1]
+        # lS_o (one index per bag: offsets = arange(B), :418) is implied by the [F, B] layout
+        assert np.array_equal(g[f"lS_o_{k}"], np.tile(np.arange(ids.shape[1]), (ids.shape[0], 1)))
+
+    train = cd.BinaryCTRDataset(num_fields=26, split="train", **paths)
+    test = cd.BinaryCTRDataset(num_fields=26, split="test", **paths)
+    assert train.counts == [int(c) for c in np.diff(g["count_file"])]
+    k = -1
+    for k, b in enumerate(train.batches(B, device="cpu")):
+        check(b, k)
+    assert k == 5
+    check(next(test.batches(B, device="cpu")), 6)
+    whole = cd.BinaryCTRDataset(num_fields=26, split="train", train_len=S, **paths)             # the reference's split
+    for k, b in enumerate(whole.batches(B, device="cpu")):
+        check(b, k)
+    assert k == nb - 1
