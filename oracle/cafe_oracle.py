@@ -23,8 +23,8 @@ _u8p = ctypes.POINTER(ctypes.c_uint8)
 def build(force=False):
     """Compile liboracle.so (and, where /root/reference exists, oracle/_ref) with the committed Makefile."""
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "cafe_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "cafe_oracle.c"), os.path.join(_HERE, "cafe_oracle_ae.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.exists("/root/reference/tricks/sketch.cpp"):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -53,6 +53,17 @@ def _lib():
         L.cafe_oracle_dump.argtypes = [ctypes.c_void_p, _i32p, _f32p, _i32p, _u8p, _i32p, _f32p, _i32p, _i32p, _u8p, _u32p]
         L.cafe_oracle_load.argtypes = [ctypes.c_void_p, _i32p, _f32p, _i32p, _u8p, _i32p, _f32p, _i32p, _i32p, _u8p, _u32p,
                                        ctypes.c_long, ctypes.c_float, _i32p, ctypes.c_double]
+        _u32 = _u32p
+        L.cafe_oracle_ae_create.restype = ctypes.c_void_p
+        L.cafe_oracle_ae_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double]
+        L.cafe_oracle_ae_destroy.argtypes = [ctypes.c_void_p]
+        L.cafe_oracle_ae_batch_query.argtypes = [ctypes.c_void_p, _u32, ctypes.c_int, _i32p]
+        L.cafe_oracle_ae_batch_insert_val.argtypes = [ctypes.c_void_p, _u32, _f32p, ctypes.c_int, _i32p]
+        L.cafe_oracle_ae_update.argtypes = [ctypes.c_void_p]
+        L.cafe_oracle_ae_dims.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
+        L.cafe_oracle_ae_tot.restype = ctypes.c_double
+        L.cafe_oracle_ae_tot.argtypes = [ctypes.c_void_p]
+        L.cafe_oracle_ae_dump.argtypes = [ctypes.c_void_p, _u32, _f32p, _i32p, _u32]
         _LIB = L
     return _LIB
 
@@ -135,6 +146,70 @@ class Oracle:
         self.L.cafe_oracle_stats(ctypes.c_void_p(self.h), out)
         names = ("main_hit", "lru_hit", "lru_miss", "evict_move", "promote", "move_fail", "push_back", "pop_empty")
         return dict(zip(names, (int(x) for x in out)))
+
+
+class AEOracle:
+    """The earlier HotSketch generation (ArtifactEvaluation/embeddings/sketch.cpp, class SS): one instance = one field."""
+
+    def __init__(self, lim, threshold, decay_rate):
+        self.L = _lib()
+        self.h = self.L.cafe_oracle_ae_create(int(threshold), int(lim), float(decay_rate))
+
+    def __del__(self):
+        try:
+            self.L.cafe_oracle_ae_destroy(self.h)
+        except Exception:
+            pass
+
+    def insert_val(self, ids, v=None):
+        ids = _ids(ids)
+        ins = np.zeros(max(len(ids), 1), np.int32)
+        vp = None
+        if v is not None:
+            v = np.ascontiguousarray(v, np.float32)
+            vp = v.ctypes.data_as(_f32p)
+        self.L.cafe_oracle_ae_batch_insert_val(self.h, ids.ctypes.data_as(_u32p), vp, len(ids), ins.ctypes.data_as(_i32p))
+        return ins[:len(ids)]
+
+    def insert(self, ids):
+        return self.insert_val(ids, None)
+
+    def query(self, ids):
+        ids = _ids(ids)
+        que = np.zeros(max(len(ids), 1), np.int32)
+        self.L.cafe_oracle_ae_batch_query(self.h, ids.ctypes.data_as(_u32p), len(ids), que.ctypes.data_as(_i32p))
+        return que[:len(ids)]
+
+    def update(self):
+        self.L.cafe_oracle_ae_update(self.h)
+
+    def state(self):
+        d = (ctypes.c_int64 * 4)()
+        self.L.cafe_oracle_ae_dims(self.h, d)
+        s, flen, num, decays = (int(x) for x in d)
+        st = {"val": np.zeros(s * 4, np.uint32), "cnt": np.zeros(s * 4, np.float32), "dic": np.zeros(s * 4, np.int32),
+              "fifo": np.zeros(max(flen, 1), np.uint32)}
+        self.L.cafe_oracle_ae_dump(self.h, st["val"].ctypes.data_as(_u32p), st["cnt"].ctypes.data_as(_f32p),
+                                   st["dic"].ctypes.data_as(_i32p), st["fifo"].ctypes.data_as(_u32p))
+        st["fifo"] = st["fifo"][:flen]
+        st["num"], st["decays"], st["tot"] = num, decays, float(self.L.cafe_oracle_ae_tot(self.h))
+        return st
+
+
+def ae_states_equal(a, b):
+    """Bit-exact comparison of two AE-generation state dumps; list of differences."""
+    bad = []
+    for k in ("val", "dic", "fifo"):
+        if not np.array_equal(np.asarray(a[k]), np.asarray(b[k])):
+            bad.append(k)
+    if not np.array_equal(np.asarray(a["cnt"], np.float32).view(np.uint32), np.asarray(b["cnt"], np.float32).view(np.uint32)):
+        bad.append("cnt")
+    for k in ("num", "decays"):
+        if int(a[k]) != int(b[k]):
+            bad.append(f"{k}: {a[k]} vs {b[k]}")
+    if np.float64(a["tot"]).view(np.uint64) != np.float64(b["tot"]).view(np.uint64):
+        bad.append(f"tot: {a['tot']!r} vs {b['tot']!r}")
+    return bad
 
 
 def read_state(L, prefix, h=None):
