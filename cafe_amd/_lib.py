@@ -42,6 +42,19 @@ SYMBOLS = {
     "cafe_sketch_counters": (ctypes.c_int, [_vp, _i64p]),
     "cafe_sketch_fallback_reasons": (ctypes.c_int, [_vp, _vp]),
     "cafe_sketch_clock_renorms": (ctypes.c_int, [_vp, _vp]),
+    "cafe_ae_create": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double]),
+    "cafe_ae_destroy": (ctypes.c_int, [_vp]),
+    "cafe_ae_insert_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp]),
+    "cafe_ae_query_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "cafe_ae_update": (ctypes.c_int, [_vp, _vp]),
+    "cafe_ae_dims": (ctypes.c_int, [_vp, _vp]),
+    "cafe_ae_export": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "cafe_ae_import": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int]),
+    "cafe_ae_ref_init": (None, [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]),
+    "cafe_ae_ref_batch_query": (_i32p, [_u32p, ctypes.c_int, ctypes.c_int]),
+    "cafe_ae_ref_batch_insert": (_i32p, [_u32p, ctypes.c_int, ctypes.c_int]),
+    "cafe_ae_ref_batch_insert_val": (_i32p, [_u32p, _f32p, ctypes.c_int, ctypes.c_int]),
+    "cafe_ae_ref_update": (None, [ctypes.c_int]),
     "cafe_query_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "cafe_query_median_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "cafe_insert_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp]),

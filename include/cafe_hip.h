@@ -212,6 +212,46 @@ int cafe_backward_sgd_gid_strided_dev(cafe_tables_t *t, const int32_t *d_fields,
 int cafe_grad_norm_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_norms, float *d_field_sums,
                        cafe_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (E) The earlier HotSketch generation of the reference's artifact (ArtifactEvaluation/embeddings/sketch.cpp:9-151,
+ *     class SS): `n` buckets of four slots kept sorted by score, bucket = id % n, a multiplicative decay() instead of
+ *     the lazy flip bit, no LRU table; one instance per field (the reference keeps ss[26], :152).  Same contract as
+ *     (B): device pointers, a stream, results bit-exact with the reference's in-order loop (ins[], que[], every slot,
+ *     the free list in pop order, num, and tot -- the double the reference accumulates item by item).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct cafe_ae_sketch cafe_ae_sketch_t;
+/* :207-209 init(n, Threshold, dr, idx) -> new SS(Threshold, n, dr) (:26-43). */
+int cafe_ae_create(cafe_ae_sketch_t **out, int n, int threshold, double decay_rate);
+int cafe_ae_destroy(cafe_ae_sketch_t *s);
+/* :135-151 batch_insert / batch_insert_val (d_vals == NULL: every score is 1): decay() first if the scores inserted
+ * since the last decay exceed n * Threshold * 10, then Insert (:89-124) for every id in order.  d_ins[i] = 1 if the id
+ * took a hot slot at this item.  Any n (the reference's own result buffers hold 16384, :7). */
+int cafe_ae_insert_dev(cafe_ae_sketch_t *s, const int32_t *d_ids, const float *d_vals, int n, int32_t *d_ins,
+                       cafe_stream_t stream);
+/* :125-134 batch_query: -slot if the id holds a hot slot, else the id. */
+int cafe_ae_query_dev(cafe_ae_sketch_t *s, const int32_t *d_ids, int n, int32_t *d_que, cafe_stream_t stream);
+/* :61-75 update(): the free list becomes the ascending slot numbers 1..n-1 that no entry holds.  (The reference clears
+ * only the first 8 bytes of its marker array -- memset(v, 0, sizeof(v)) on a pointer -- so its own result depends on
+ * what operator new returned; this is the intended semantics.) */
+int cafe_ae_update(cafe_ae_sketch_t *s, cafe_stream_t stream);
+/* State for checkpoints and parity tests.  out5: buckets, free-list length, num, decay() calls so far, batches that
+ * ran in order because the free list ran dry inside them.  export/import: val, cnt, dic [n * 4] (the id of an empty
+ * slot, never initialised by the reference, is reported as 0), the free list in pop order, tot. */
+int cafe_ae_dims(cafe_ae_sketch_t *s, int64_t *out5);
+int cafe_ae_export(cafe_ae_sketch_t *s, uint32_t *val, float *cnt, int32_t *dic, uint32_t *fifo, double *tot);
+int cafe_ae_import(cafe_ae_sketch_t *s, const uint32_t *val, const float *cnt, const int32_t *dic, const uint32_t *fifo,
+                   int fifo_len, double tot, int num);
+/* The artifact's own C entry points on HOST pointers (:207-228: init, batch_query, batch_insert, batch_insert_val,
+ * update, each with the field index as last argument), under a prefix because tricks/sketch.cpp's entry points of the
+ * same names and other signatures (section A) live in this library too; INTEGRATION.md shows the three-line ctypes
+ * shim that binds them under the reference's names.  Results are returned in library-owned storage like the
+ * reference's static arrays. */
+void cafe_ae_ref_init(int n, int Threshold, double dr, int idx);
+int *cafe_ae_ref_batch_query(uint32_t *data, int len, int idx);
+int *cafe_ae_ref_batch_insert(uint32_t *data, int len, int idx);
+int *cafe_ae_ref_batch_insert_val(uint32_t *data, float *v, int len, int idx);
+void cafe_ae_ref_update(int idx);
+
 #ifdef __cplusplus
 }
 #endif

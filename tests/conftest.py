@@ -14,7 +14,8 @@ def pytest_configure(config):
 
 def golden_names():
     g = os.path.join(ROOT, "tests", "golden")
-    return sorted(f[:-4] for f in os.listdir(g) if f.endswith(".npz") and not f.startswith("module_"))
+    other = ("module_", "ae_", "loader_", "pinsage_")       # fixtures of other tests (module steps, AE generation, loader, state file)
+    return sorted(f[:-4] for f in os.listdir(g) if f.endswith(".npz") and not f.startswith(other))
 
 
 def module_golden_names():
