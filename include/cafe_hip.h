@@ -90,19 +90,22 @@ int cafe_sketch_load(cafe_sketch_t *s, const char *path);
 /* Rebuild the free list from the tables (see `update` above). */
 int cafe_sketch_rebuild_free_list(cafe_sketch_t *s, cafe_stream_t stream);
 
-/* Options: "serial_insert" (1 = always use the one-lane in-order kernel), "max_rounds" (fix-point rounds of the
- * parallel insert before it gives the batch to the in-order kernel), "target_items" (ids per bucket-owner
- * workgroup), "hot_bypass" (0 = ids that are already hot go through the owner rounds too), "overlap" (bit 0: the
- * score-independent head of an insert, bit 1: the backward's partition passes run on the handle's second stream;
- * 0 = one stream), "exact_reset" (1 = the host's bound on real_n counts every issued id as a possible threshold
- * crossing: waits for the device more often, never estimates), "fuse_fields" (0 = cafe_backward_update_dev with
- * per_field always issues field by field), "verify" (0 = a step that may hold a reset boundary is issued field by
- * field from the start instead of as one insert the device checks before committing). */
+/* Options (tuning and test aids; results never depend on them): "serial_insert" (1 = always use the one-lane in-order
+ * kernel), "max_rounds" (rounds the fix-point kernel of the parallel insert may take before the batch counts as not
+ * settled; default 6), "target_items" (ids per bucket-owner workgroup, default 320), "hot_bypass" (0 = ids that are
+ * already hot go through the owner rounds too), "hot_table" (1 = sort-free hot owner with a per-wave LDS slot table),
+ * "owner_cap" (1024 / 2048 / 8192 = fixed owner capacity; 0 = chosen from the last batch's largest partition),
+ * "plan_ahead" (0 = cafe_forward_dev does not plan the insert that follows), "overlap" (bit 0: the plan of an insert,
+ * bit 1: the update's partition passes run on the handle's second stream; 0 = one stream), "fuse_fields" (0 =
+ * cafe_backward_update_dev with per_field always issues field by field), "verify", "move_cap" (moves one main
+ * partition accepts per round, at most 512: a test aid), "exact_reset" (accepted and ignored: the reset decision is
+ * always made on the exact real_n, on the device). */
 int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int value);
 /* Counters since creation: [0] insert calls, [1] calls finished by the parallel path, [2] calls given
  * to the in-order kernel, [3] fix-point rounds used in total, [4] resets, [5] largest round count, [6] call
- * boundaries at which the reference would have reset but the host's estimate of real_n said no (expected 0; the
- * reset then happens at the next boundary), [7] times the host waited for the exact real_n. */
+ * boundaries at which the reference would have reset and this library did not: 0 by construction (the test of
+ * sketch.cpp:291 is made on the device's exact real_n at every boundary, before anything is applied), kept as a
+ * check the tests assert, [7] times the host waited for a snapshot of the device state (once per fused step). */
 int cafe_sketch_counters(cafe_sketch_t *s, int64_t *out8);
 /* Why batches left the parallel path (given to the in-order kernel, or -- cafe_backward_update_dev -- rejected before
  * anything was applied and issued again), since creation: [0] a workspace limit (partition larger than an owner can
@@ -183,12 +186,18 @@ int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, const int32_t
  * host call; d_scores / d_ins [num_fields*batch] are outputs.
  * per_field != 0: the sketch sees what the reference's loop over fields gives it (dlrm_s_pytorch.py:734-738): one
  *   batch_insert_val per field, i.e. decay and batch counter advance once per field and the reset test of
- *   sketch.cpp:291 applies at every field boundary.  When no flip and no reset can fall on an inner boundary the
- *   fields still run as ONE parallel insert (identical state and ins[], since the calls walk consecutive parts of
- *   the same id stream); otherwise the step is issued field by field.  The one-insert form evaluates migration
- *   once, after the last field; that equals field-by-field migration as long as Threshold > 1, and steps that
- *   run while Threshold <= 1 are issued field by field.
- * per_field == 0: ONE batch_insert_val over all fields' ids in field-major order. */
+ *   sketch.cpp:291 applies at every field boundary.  The fields still run as ONE parallel insert (identical state and
+ *   ins[], since the calls walk consecutive parts of the same id stream) unless the host's own counters show a decay
+ *   flip inside the step or Threshold <= 1 (migration then depends on the state after each field); such
+ *   steps are issued field by field.  Whether the reset test fires at an inner boundary is decided on the device, from
+ *   the exact real_n and per-field crossing counts, BEFORE anything is applied: such a step is rejected and issued again
+ *   field by field inside this call, as is a step the parallel insert could not settle (first with the largest
+ *   owners).  The call therefore WAITS for the device's verdict on the insert (a snapshot in pinned host memory; the
+ *   migration and update kernels are queued behind the insert beforehand and do nothing for a rejected step); when it
+ *   returns, the remaining kernels are enqueued on `stream` as usual.
+ * per_field == 0: ONE batch_insert_val over all fields' ids in field-major order.
+ * cafe_forward_dev starts the plan of this insert beside its gather kernel when it is called with d_local_ids; the
+ * plan is used if this call follows with the same d_local_ids and no sketch call in between. */
 int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
                              const int32_t *d_que, const float *d_grad_out, int batch, float lr, float *d_scores,
                              int32_t *d_ins, int per_field, cafe_stream_t stream);
