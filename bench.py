@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--repetitions", type=int, default=20,
                     help="the timed window of --steps steps is run this many times back to back; the line reports the median "
                          "window (min and max beside it)")
+    ap.add_argument("--ids-on-stream", action="store_true",
+                    help="do NOT tell the library that a batch's ids are resident before forward is called (they are: the bench "
+                         "holds every id batch in HBM before the timed region); the plan of the insert then waits for everything "
+                         "queued on the stream instead of starting at once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -197,6 +201,8 @@ def main():
         eng = ShardedCafeEmbedding(wl.counts, D, wl.hotn, wl.hash_sizes, wl.offsets, threshold=wl.threshold,
                                    alpha=wl.alpha, seed=1)
 
+    if world == 1 and not args.ids_on_stream:
+        eng.sketch.set_option("ids_ready", 1)
     nb = args.id_batches
     ids_host = wl.make_ids(123 + rank, steps=nb, a=args.zipf_a)
     ids_dev = [torch.from_numpy(ids_host[i]).cuda() for i in range(nb)]
@@ -343,6 +349,7 @@ def main():
                                          "loop": "one per field, issued one by one", False: "one per step"}[cadence]),
                        "parallelism": "single GPU" if world == 1 else f"id-hash sharded x{world}, RCCL all-to-all",
                        "host_syncs_in_step": getattr(eng, "host_syncs_in_step", 0),
+                       "ids_ready": int(world == 1 and not args.ids_on_stream),
                        "preheat_steps": args.preheat, "id_batches": nb, "drift": args.drift, "repetitions": reps,
                        "cadence_miss": (eng.sketch.counters()["cadence_miss"] if getattr(eng, "sketch", None) else None)},
             "window_ms": {"median": round(dt * 1e3, 4), "min": round(windows[0] * 1e3, 4), "max": round(windows[-1] * 1e3, 4),

@@ -2,6 +2,7 @@
 // routed row gather (forward), importance scores from the output gradient, cold->hot row migration, and
 // the sparse backward + SGD update.  Behaviour follows tricks/sk_embedding_bag.py (cited per kernel).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstring>
 
 #include <algorithm>
@@ -228,7 +229,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     // Training steps: the plan of the insert that will follow (it reads the ids and the same pre-batch tables the gather
     // reads) runs beside the gather on the sketch's second stream, behind everything queued on `st` so far.  Stopped
     // when forwards come without updates (inference), resumed by the next cafe_backward_update_dev.
-    bool plan = false;
+    bool plan = false, plan_launched = false;
     if (d_local_ids && s->opt_plan_ahead && s->opt_overlap && !s->opt_serial && s->opt_fuse_fields && s->side_stream &&
         s->side_stream != st && total >= 32768 && total <= cafe::kParMaxIds && t->num_fields <= kMaxSeg) {
         if (s->plan_valid) s->unused_plans++;
@@ -236,15 +237,31 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
         const bool reset_due = s->adjust && (double)cafe::real_n_bound(s) > s->lim * 1.2;
         if (s->unused_plans < 2 && !reset_due) {
             if (cafe::par_prepare(s, total)) return 1;
-            CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, st));
-            CAFE_HIP_CHECK(hipStreamWaitEvent(s->side_stream, s->ev_head_fork, 0));
+            // What the plan reads must be final: the sketch (the last insert's commit) and the ids.  Normally that means
+            // "behind everything queued on st so far".  With option ids_ready the caller promises that the ids were
+            // written before this call was made (a data loader's batch, not the output of a kernel still queued on st);
+            // if the host has also seen the last insert's snapshot (cafe_backward_update_dev waits for it), nothing is
+            // left to wait for: the plan starts at once, beside the previous step's update kernels instead of beside
+            // this gather.
+            if (s->opt_ids_ready && s->call_seq == s->base_seq) {
+                if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream)) return 1;
+                plan_launched = true;
+            } else {
+                CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, st));
+                CAFE_HIP_CHECK(hipStreamWaitEvent(s->side_stream, s->ev_head_fork, 0));
+            }
             plan = true;
         }
     }
+    // the kernel's own completion signal is the event the update's partition passes wait for on the second stream (no
+    // marker packet on `st` between the gather and the norm kernel)
+    hipEvent_t fwd_done = s->ev_fwd;
+    s->fwd_que = d_que;
 #define CAFE_FWD(L)                                                                                              \
-    hipLaunchKernelGGL((k_forward<L, false>), dim3(blocks), dim3(256), 0, st, s->d_main, fm1, t->d_w_hot, t->d_w_cold, \
-                       t->d_id_offset, t->d_hash_size, d_local_ids, d_in_gids, d_fields, batch, total, t->dim, t->hotn, d_gids, d_que, \
-                       d_out, (const float *)nullptr, 1, (const DevState *)nullptr, 0, (int32_t *)nullptr)
+    hipExtLaunchKernelGGL((k_forward<L, false>), dim3(blocks), dim3(256), 0, st, nullptr, fwd_done, 0,           \
+                          (const MainBucket *)s->d_main, fm1, (const float *)t->d_w_hot, (float *const *)t->d_w_cold, \
+                          (const int64_t *)t->d_id_offset, (const int32_t *)t->d_hash_size, d_local_ids, d_in_gids, d_fields, batch, total, \
+                          t->dim, t->hotn, d_gids, d_que, d_out, (const float *)nullptr, 1, (const DevState *)nullptr, 0, (int32_t *)nullptr)
     if (t->timing) (void)hipEventRecord(t->ev_t[0][0], st);
     switch (lpg) {
         case 1: CAFE_FWD(1); break;
@@ -258,7 +275,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
 #undef CAFE_FWD
     if (t->timing) (void)hipEventRecord(t->ev_t[0][1], st);
     CAFE_HIP_CHECK(hipGetLastError());
-    if (plan) {
+    if (plan && !plan_launched) {
         if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream)) return 1;
     }
     s->host_us[0] += now_us() - t_begin;
@@ -1030,8 +1047,14 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
         bool plan_done = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (side != st) {
-                CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, st));
-                CAFE_HIP_CHECK(hipStreamWaitEvent(side, s->ev_head_fork, 0));
+                // the second stream continues behind the forward that produced this routing (its own completion event),
+                // or, for a routing of unknown origin, behind everything queued on st
+                if (attempt == 0 && s->fwd_que == d_que && s->fwd_que) {
+                    CAFE_HIP_CHECK(hipStreamWaitEvent(side, s->ev_fwd, 0));
+                } else {
+                    CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, st));
+                    CAFE_HIP_CHECK(hipStreamWaitEvent(side, s->ev_head_fork, 0));
+                }
             }
             int nparts = 0;
             if (attempt == 0) {

@@ -380,6 +380,7 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_fork, kDeviceEvent));
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_join, kDeviceEvent));
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_plan, kDeviceEvent));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fwd, kDeviceEvent));
     if (s->ws_misc.reserve(4096)) return 1;
     CAFE_HIP_CHECK(hipMemset(s->d_main, 0, sizeof(MainBucket) * (size_t)s->n1));
     CAFE_HIP_CHECK(hipMemset(s->d_lru, 0, sizeof(LruBucket) * (size_t)s->n2));
@@ -401,6 +402,7 @@ extern "C" int cafe_sketch_destroy(cafe_sketch_t *s) {
     if (s->ev_head_fork) (void)hipEventDestroy(s->ev_head_fork);
     if (s->ev_head_join) (void)hipEventDestroy(s->ev_head_join);
     if (s->ev_plan) (void)hipEventDestroy(s->ev_plan);
+    if (s->ev_fwd) (void)hipEventDestroy(s->ev_fwd);
     s->ws_reset_keys.release(); s->ws_reset_keys2.release(); s->ws_reset_tmp.release();
     s->ws_reset_flags.release(); s->ws_misc.release();
     delete s;
@@ -416,6 +418,7 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
     else if (!strcmp(name, "hot_table")) s->opt_hot_table = value ? 1 : 0;
     else if (!strcmp(name, "plan_ahead")) s->opt_plan_ahead = value ? 1 : 0;
     else if (!strcmp(name, "move_cap")) s->opt_move_cap = value;
+    else if (!strcmp(name, "ids_ready")) s->opt_ids_ready = value ? 1 : 0;
     else if (!strcmp(name, "owner_cap")) s->force_cap = value == 1024 || value == 2048 || value == 8192 ? value : 0;
     else if (!strcmp(name, "overlap")) s->opt_overlap = value;
     else if (!strcmp(name, "fuse_fields")) s->opt_fuse_fields = value ? 1 : 0;

@@ -14,6 +14,9 @@ from cafe_amd.collection import CafeEmbeddingCollection
 wl = workload(sys.argv[1] if len(sys.argv) > 1 else "cfg3")
 F, B, D = wl.num_fields, wl.batch, wl.dim
 eng = CafeEmbeddingCollection(wl.counts, D, wl.hotn, wl.hash_sizes, wl.offsets, threshold=wl.threshold, alpha=wl.alpha, seed=1)
+import os
+if os.environ.get("IDS_READY", "1") == "1":
+    eng.sketch.set_option("ids_ready", 1)
 ids = [torch.from_numpy(x).cuda() for x in wl.make_ids(123, steps=16)]
 grad = torch.randn(F, B, D, device="cuda")
 out = torch.empty(F, B, D, device="cuda")
