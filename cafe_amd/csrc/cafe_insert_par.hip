@@ -127,7 +127,9 @@ struct Geo {
     int sseg;                   // > 0: ids per field for the score scaling (Score::psum)
     int nparts;                 // partial sums per field behind Score::psum
     int prof;                   // diagnostic builds: stamp slot of the kernel
-    int cap_ev;                 // moves one main partition accepts per round (<= kCapEv; smaller in tests)
+    int cap_ev;                 // moves one main partition accepts per round (<= evs; smaller in tests)
+    int evs, evls;              // move-list slots per main partition (in) and per LRU partition (out): kCapEv / kCapEvL,
+                                // eight times that when a small table is cut into few, large partitions
     FastMod fm1, fm2;
 };
 
@@ -974,8 +976,8 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
     }
     const int total = np + ne;
     if (total > CAP) { if (tid == 0) A.ctl->overflow = 1; return; }
-    const size_t evbase = (size_t)prev * g.P1 * kCapEv + (size_t)p * kCapEv;          // this round's moves
-    const size_t evold = (size_t)(prev ^ 1) * g.P1 * kCapEv + (size_t)p * kCapEv;     // the moves of the round before
+    const size_t evbase = (size_t)prev * g.P1 * g.evs + (size_t)p * g.evs;          // this round's moves
+    const size_t evold = (size_t)(prev ^ 1) * g.P1 * g.evs + (size_t)p * g.evs;     // the moves of the round before
     if (MOVES) {
         // Same moves as the last round this partition ran with => same result: its staged buckets, per-item
         // outcomes and move outcomes stand.  Lists are compared as sets (arrival order is not deterministic).
@@ -1078,7 +1080,7 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
     CAFE_STAMP(g.prof, 3);
     const float thr = A.st->thr;
     const uint32_t gflip = (uint32_t)A.st->flip;
-    MainBucket *stage = A.stage_m + o0 + (size_t)p * kCapEv;
+    MainBucket *stage = A.stage_m + o0 + (size_t)p * g.evs;
     MainCtx ctx;
     ctx.full = A.st->fifo_len > 0;
     int changed = 0;
@@ -1314,7 +1316,7 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
     const uint32_t o0 = A.off[off_lru0(g) + q], o1 = A.off[off_lru0(g) + q + 1];
     const int cnt = (int)(o1 - o0);
     if (cnt > CAP) { if (tid == 0) A.ctl->overflow = 1; return; }
-    MoveEv *mine_ev = A.myev + (size_t)q * kCapEvL;
+    MoveEv *mine_ev = A.myev + (size_t)q * g.evls;
     const bool dirty = round == 1 || A.ldirty[par * g.P2 + q];
     if (tid == 0) A.ldirty[nxt * g.P2 + q] = 0;
     if (!dirty) {
@@ -1325,7 +1327,7 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
             const MoveEv m = mine_ev[j];
             const int p = m.pad[0];
             uint32_t at = atomicAdd(&A.evcnt[par * g.P1 + p], 1u);
-            if (at < (uint32_t)g.cap_ev) A.ev[(size_t)par * g.P1 * kCapEv + (size_t)p * kCapEv + at] = m; else A.ctl->overflow = 1;
+            if (at < (uint32_t)g.cap_ev) A.ev[(size_t)par * g.P1 * g.evs + (size_t)p * g.evs + at] = m; else A.ctl->overflow = 1;
         }
         return;
     }
@@ -1413,9 +1415,9 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
                 m.time = 2u * pos + 1u; m.x = mv.x; m.cnt = mv.cnt; m.dic = mv.dic; m.kind = mv.kind;
                 m.pad[0] = p; m.pad[1] = m.pad[2] = 0;
                 uint32_t at = atomicAdd(&A.evcnt[par * g.P1 + p], 1u);
-                if (at < (uint32_t)g.cap_ev) A.ev[(size_t)par * g.P1 * kCapEv + (size_t)p * kCapEv + at] = m; else over = 1;
+                if (at < (uint32_t)g.cap_ev) A.ev[(size_t)par * g.P1 * g.evs + (size_t)p * g.evs + at] = m; else over = 1;
                 int mi = atomicAdd(n_ev, 1);
-                if (mi < kCapEvL) mine_ev[mi] = m; else over = 1;
+                if (mi < g.evls) mine_ev[mi] = m; else over = 1;
             }
         }
         store_lru(&stage[s], b, b0 + (int)bl);
@@ -1480,9 +1482,9 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
                         mm.time = 2u * pos + 1u; mm.x = mv.x; mm.cnt = mv.cnt; mm.dic = mv.dic; mm.kind = mv.kind;
                         mm.pad[0] = p; mm.pad[1] = mm.pad[2] = 0;
                         uint32_t at = atomicAdd(&A.evcnt[par * g.P1 + p], 1u);
-                        if (at < (uint32_t)g.cap_ev) A.ev[(size_t)par * g.P1 * kCapEv + (size_t)p * kCapEv + at] = mm; else over = 1;
+                        if (at < (uint32_t)g.cap_ev) A.ev[(size_t)par * g.P1 * g.evs + (size_t)p * g.evs + at] = mm; else over = 1;
                         int mi = atomicAdd(n_ev, 1);
-                        if (mi < kCapEvL) mine_ev[mi] = mm; else over = 1;
+                        if (mi < g.evls) mine_ev[mi] = mm; else over = 1;
                     }
                 }
                 e += 1;
@@ -1493,7 +1495,7 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
     __syncthreads();
     CAFE_STAMP(g.prof, 4);
     if (tid == 0) {
-        A.mycnt[q] = (uint32_t)min(*n_ev, kCapEvL);
+        A.mycnt[q] = (uint32_t)min(*n_ev, g.evls);
         if (round == 1 && *n_ev) atomicAdd(&A.ctl->nmoves, (uint32_t)*n_ev);
     }
     for (int s = tid; s < nmiss; s += kThreads) {
@@ -1846,11 +1848,11 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
             int tot = (int)A.stage_tot[part];
             // Everything below indexes the tables with numbers read from the staging buffers.  They are written by the
             // owners of this very call; the range checks turn a broken invariant into a counted refusal, not a wild store.
-            const int room = part < g.P1 ? (int)(A.off[2 * part + 2] - A.off[2 * part]) + kCapEv
+            const int room = part < g.P1 ? (int)(A.off[2 * part + 2] - A.off[2 * part]) + g.evs
                                          : (int)(A.off[off_lru0(g) + (part - g.P1) + 1] - A.off[off_lru0(g) + (part - g.P1)]);
             if (tot < 0 || tot > room) { if (tid == 0) atomicAdd(&st->bad_commit, 1); tot = 0; }
             if (part < g.P1) {
-                const MainBucket *stage = A.stage_m + A.off[2 * part] + (size_t)part * kCapEv;
+                const MainBucket *stage = A.stage_m + A.off[2 * part] + (size_t)part * g.evs;
                 for (int s = tid; s < tot; s += blockDim.x) {
                     const int4 *p = reinterpret_cast<const int4 *>(&stage[s]);
                     const int4 m = p[3];
@@ -2006,12 +2008,15 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     g.n = n; g.n1 = s->n1; g.n2 = s->n2;
     pick_parts(n, s->n1, s->opt_target_items, g.P1, g.bpp1);
     pick_parts(n, s->n2, s->opt_target_items, g.P2, g.bpp2);
+    // few partitions (a small sketch fed a large batch): each of them sees a large share of the batch's moves
+    g.evs = g.P1 <= 128 ? 8 * kCapEv : kCapEv;
+    g.evls = g.P2 <= 128 ? 8 * kCapEvL : kCapEvL;
+    g.cap_ev = std::min(std::max(s->opt_move_cap, 1), g.evs);
     g.fm1 = make_fastmod(s->n1);
     g.fm2 = make_fastmod(s->n2);
     g.bits1 = ilog2_ceil(g.bpp1);
     g.bits2 = ilog2_ceil(g.bpp2);
     g.nchunks = (n + kChunk - 1) / kChunk;
-    g.cap_ev = std::min(std::max(s->opt_move_cap, 1), kCapEv);
     // hot list: partitions small enough for the per-wave slot table if the plan's histogram has room for them, else
     // the main table's partitions (sorted by the owner)
     g.hot = s->opt_hot_bypass ? 1 : 0;
@@ -2032,11 +2037,11 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     if (w.ctl.reserve(4 * (kCtlWords + 2 * (size_t)kMaxParts + 16)) || w.cm.reserve(2 * mat + 16) || w.colpref.reserve(4 * mat + 16) ||
         w.tot.reserve(4 * (size_t)g.nbins + 16) || w.off.reserve(4 * ((size_t)g.nbins + 8)) || w.plan.reserve(8 * N + 16) ||
         w.items.reserve(3 * sizeof(Rec) * N + 64) || w.hkey.reserve(8 * N + 16) || w.hrun.reserve(4 * N + 16) || w.hfin.reserve(8 * N + 16) ||
-        w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * kCapEv) || w.evres.reserve(sizeof(EvRes) * N + 64) || w.miss.reserve(N + 16) ||
+        w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * g.evs) || w.evres.reserve(sizeof(EvRes) * N + 64) || w.miss.reserve(N + 16) ||
         w.outm.reserve(N + 16) || w.outl.reserve(N + 16) ||
-        w.stage_m.reserve(sizeof(MainBucket) * (N + (size_t)g.P1 * kCapEv)) || w.stage_l.reserve(sizeof(LruBucket) * N + 128) ||
+        w.stage_m.reserve(sizeof(MainBucket) * (N + (size_t)g.P1 * g.evs)) || w.stage_l.reserve(sizeof(LruBucket) * N + 128) ||
         w.stage_tot.reserve(4 * PP + 4) || w.prevcnt.reserve(4 * (size_t)g.P1 + 4) || w.ldirty.reserve(2 * (size_t)g.P2 + 4) ||
-        w.myev.reserve(sizeof(MoveEv) * (size_t)g.P2 * kCapEvL) || w.mycnt.reserve(4 * (size_t)g.P2 + 4) || w.flags.reserve(5 * N + 64) ||
+        w.myev.reserve(sizeof(MoveEv) * (size_t)g.P2 * g.evls) || w.mycnt.reserve(4 * (size_t)g.P2 + 4) || w.flags.reserve(5 * N + 64) ||
         w.agg.reserve(16 * (size_t)nblocks + 16) || w.ranks.reserve(12 * N + 16) || w.gotlist.reserve(4 * N + 16))
         return 1;
     if (w.evres.p != w.evres_seen || w.evres.cap != w.evres_seen_cap) {      // tags of a fresh allocation must not match by accident
@@ -2068,8 +2073,24 @@ static int pick_cap(cafe_sketch *s, int n) {
     // which take any partition up to 8192 items; sizes that wander by a few percent (a shard's share of a step) keep
     // using the snapshot, whose margin below covers them
     const long ref_n = s->last_seen_batch;
-    if (m->seq == 0 || (long)n * 4 > ref_n * 5 || (long)n * 4 < ref_n * 3) { s->last_seen_batch = n; return 8192; }
-    const long big = std::max(m->st.maxpart, s->opt_hot_table ? 0 : m->st.pad[3]);       // (hot partitions of the table form have no limit)
+    if (m->seq == 0 || (long)n * 4 > ref_n * 5 || (long)n * 4 < ref_n * 3) {
+        s->last_seen_batch = n;
+        for (int i = 0; i < 32; ++i) s->cap_hist[i] = 0;
+        s->cap_hist_at = 0;
+        s->cap_regime_seq = s->call_seq;         // snapshots of earlier calls belong to the previous regime
+        return 8192;
+    }
+    // the largest partition over the last 32 snapshots of this regime, not just the last one: callers that alternate
+    // between differently distributed streams (one call per field) would otherwise size the owners for the previous
+    // field, and a batch that does not fit goes to the in-order kernel (~1.3 us per id)
+    const long big_now = std::max(m->st.maxpart, s->opt_hot_table ? 0 : m->st.pad[3]);
+    if (m->seq != s->cap_seen_seq && (int32_t)(m->seq - s->cap_regime_seq) >= 0) {
+        s->cap_seen_seq = m->seq;
+        s->cap_hist[s->cap_hist_at++ & 31] = (int)big_now;
+    }
+    if (s->cap_hist_at < 4) return 8192;        // too few snapshots of this regime yet (they trail the calls)
+    long big = 0;
+    for (int i = 0; i < 32; ++i) big = std::max(big, (long)s->cap_hist[i]);
     if (m->st.fallback) return 8192;
     if (big + big / 8 + 32 <= 1024) return 1024;
     if (big + big / 8 + 32 <= 2048) return 2048;
@@ -2142,7 +2163,8 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     s->plan_valid = 0;
     s->plan_stale = 0;
     if (ahead) {
-        CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_plan, 0));
+        // (a plan that has already completed -- it was started well ahead -- needs no wait packet on st)
+        if (hipEventQuery(s->ev_plan) != hipSuccess) CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_plan, 0));
         s->counters_plan_ahead++;
     } else {
         IdSrc ids;

@@ -51,7 +51,7 @@ struct cafe_sketch {
     uint32_t fifo_cap = 1;
     cafe::DevState *d_state = nullptr;
     // options / counters
-    int opt_serial = 0, opt_max_rounds = 6, opt_target_items = 320, opt_hot_bypass = 1, opt_hot_table = 0, opt_move_cap = 1 << 20, opt_ids_ready = 0;
+    int opt_serial = 0, opt_max_rounds = 6, opt_target_items = 448, opt_hot_bypass = 1, opt_hot_table = 0, opt_move_cap = 1 << 20, opt_ids_ready = 0;
     int64_t inner_reset_rejects = 0;     // fused steps the device rejected because sketch.cpp:291 fired at an inner field boundary
     int force_cap = 0;                  // option "owner_cap": items an owner workgroup can hold (0 = chosen per call)
     int force_cap_once = 0;             // ... for the call being issued (a step issued again after a workspace limit)
@@ -85,6 +85,8 @@ struct cafe_sketch {
     uint32_t base_seq = 0;              // snapshots older than this are stale (a reset or a state import came later)
     long long base_real_n = 0;          // real_n after call base_seq
     long long base_clk = 0;             // LRU clock after call base_seq
+    int cap_hist[32] = {0};             // largest partition of the last snapshots seen (owner capacity choice)
+    uint32_t cap_hist_at = 0, cap_seen_seq = 0, cap_regime_seq = 0;
     hipEvent_t ev_fwd = nullptr;        // completion of the last cafe_forward_dev gather kernel
     const void *fwd_que = nullptr;      // ... and the routing array it wrote
     uint32_t last_moves = 0;            // moves (LRU -> main) of the newest call the host has a snapshot of
