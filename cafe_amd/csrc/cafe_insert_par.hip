@@ -46,6 +46,10 @@ CAFE_KWIN_DECL(cafe_debug_windows_insert)
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kChunk = 1024;          // ids per plan workgroup
+// Smallest owner instantiation.  Its LDS (17 B per element + 0.5 KB) decides how many round-1 owners a compute unit holds
+// (the 160 KB are two halves of 80 KB and an allocation lies in one of them: measured 8 per CU up to 20 KB, 6 up to
+// 26.6 KB, 4 up to 40 KB): 1536 elements = 26.6 KB = 6 per CU = 1536 owners at once, the ~1430 of a 213 K-id batch.
+constexpr int kCapSmall = 1536;
 constexpr int kPlanThreads = 512;     // 8 waves, 256 consecutive ids each
 constexpr int kPlanWaves = kPlanThreads / 64;
 constexpr int kPlanRows = kChunk / kPlanThreads;     // rows of 64 ids a plan wave walks
@@ -691,45 +695,34 @@ __device__ inline void hot_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy,
     // chain of adds, eight scores requested from LDS ahead of their use, so the chain runs at the latency of a float
     // add per item.  Crossings (sketch.cpp:218-220) are evaluated afterwards for all items at once.
     constexpr int kLongRun = 64;
-    for (int s = tid; s < total; s += kThreads) L.s.po[s] = (s + 1 < total && L.s.sg[s + 1] == L.s.sg[s]) ? 1 : 0;
-    for (int s = total + tid; s < min(total + 4, CAP); s += kThreads) L.s.po[s] = 0;
-    __syncthreads();
+    // po[s]: bit 0 = item s + 1 belongs to the same run; bit 1 (heads only) = the run is on the heavy list
     for (int s = tid; s < total; s += kThreads) {
         const uint32_t bs = L.s.sg[s];
         const bool head = s == 0 || L.s.sg[s - 1] != bs;
-        if (!head) { fin[s] = make_int2(-1, 0); continue; }
-        if (s + kLongRun <= total && L.s.sg[s + kLongRun - 1] == bs) {
+        uint8_t f = (s + 1 < total && L.s.sg[s + 1] == bs) ? 1 : 0;
+        if (!head) {
+            fin[s] = make_int2(-1, 0);
+        } else if (s + kLongRun <= total && L.s.sg[s + kLongRun - 1] == bs) {
             const int at = atomicAdd(n_heavy, 1);
-            if (at < kMaxHeavy) { heavy[at] = s; continue; }
+            if (at < kMaxHeavy) { heavy[at] = s; f |= 2; }
         }
-        const int bucket = b0 + (int)(bs >> 2), slot = (int)(bs & 3u);
-        float acc = __uint_as_float(L.s.px[s]);
-        int e = s;
-        for (;;) {
-            // items e .. e + 3 (reads past the end of the run, or of the partition, are not used)
-            const float c0 = L.s.pc[e], c1 = L.s.pc[min(e + 1, CAP - 1)], c2 = L.s.pc[min(e + 2, CAP - 1)], c3 = L.s.pc[min(e + 3, CAP - 1)];
-            const uint8_t k0 = L.s.po[e], k1 = L.s.po[min(e + 1, CAP - 1)], k2 = L.s.po[min(e + 2, CAP - 1)], k3 = L.s.po[min(e + 3, CAP - 1)];
-            acc += c0; L.s.px[e] = __float_as_uint(acc);
-            if (!k0) break;
-            acc += c1; L.s.px[e + 1] = __float_as_uint(acc);
-            if (!k1) break;
-            acc += c2; L.s.px[e + 2] = __float_as_uint(acc);
-            if (!k2) break;
-            acc += c3; L.s.px[e + 3] = __float_as_uint(acc);
-            if (!k3) break;
-            e += 4;
-        }
-        fin[s] = make_int2(bucket * 4 + slot, __float_as_int(acc));
+        L.s.po[s] = f;
     }
+    for (int s = total + tid; s < min(total + 4, CAP); s += kThreads) L.s.po[s] = 0;
     __syncthreads();
     CAFE_STAMP(g.prof, 4);
+    // Long runs go to whole waves, the rows of 64 sorted positions (whose heads are walked by single lanes) to the waves
+    // that have no long run: a partition with one heavy id keeps one wave on that chain while the other three finish
+    // everything else beside it.  (Four or more long runs: runs and rows both round-robin over the four waves.)
     {
         const int lane = tid & 63, wave = tid >> 6;
-        const int nh = min(*n_heavy, kMaxHeavy);
-        for (int h = wave; h < nh; h += kWaves) {
-            const int s = heavy[h];
+        const int nh = min(*n_heavy, kMaxHeavy), rows = (total + 63) >> 6;
+        const bool split = nh < kWaves;
+        const int h_step = split ? kMaxHeavy : kWaves;                      // split: wave w < nh takes run w only
+        const int row0 = split ? wave - nh : wave, row_step = split ? kWaves - nh : kWaves;
+        for (int w = wave; w < nh; w += h_step) {
+            const int s = heavy[w];
             const uint32_t bs = L.s.sg[s];
-            const int bucket = b0 + (int)(bs >> 2), slot = (int)(bs & 3u);
             int r = 0;                                        // length of the run
             for (int at = s;; at += 64) {
                 const int idx = at + lane;
@@ -738,37 +731,75 @@ __device__ inline void hot_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy,
                 r += rr;
                 if (rr < 64) break;
             }
-            float acc = __uint_as_float(L.s.px[s]);
-            const float *cs = L.s.pc + s;
-            uint32_t *ws = L.s.px + s;
-            // every lane stores the same eight words (one LDS write each, no lane selection: the instruction count of the
-            // chain is what a wave pays for when it shares its SIMD with the waves of other workgroups)
-            auto put8 = [&](int at, float w0, float w1, float w2, float w3, float w4, float w5, float w6, float w7) {
-                ws[at] = __float_as_uint(w0); ws[at + 1] = __float_as_uint(w1); ws[at + 2] = __float_as_uint(w2);
-                ws[at + 3] = __float_as_uint(w3); ws[at + 4] = __float_as_uint(w4); ws[at + 5] = __float_as_uint(w5);
-                ws[at + 6] = __float_as_uint(w6); ws[at + 7] = __float_as_uint(w7);
-            };
-            int j = 0;
-            if (r >= 8) {
-                float n0 = cs[0], n1 = cs[1], n2 = cs[2], n3 = cs[3], n4 = cs[4], n5 = cs[5], n6 = cs[6], n7 = cs[7];
-                for (; j + 16 <= r; j += 8) {
-                    const float c0 = n0, c1 = n1, c2 = n2, c3 = n3, c4 = n4, c5 = n5, c6 = n6, c7 = n7;
-                    n0 = cs[j + 8]; n1 = cs[j + 9]; n2 = cs[j + 10]; n3 = cs[j + 11];
-                    n4 = cs[j + 12]; n5 = cs[j + 13]; n6 = cs[j + 14]; n7 = cs[j + 15];
-                    const float w0 = acc + c0, w1 = w0 + c1, w2 = w1 + c2, w3 = w2 + c3, w4 = w3 + c4, w5 = w4 + c5, w6 = w5 + c6, w7 = w6 + c7;
-                    acc = w7;
-                    put8(j, w0, w1, w2, w3, w4, w5, w6, w7);
+            // Every lane walks the same chain of adds (the reads are broadcasts); lane 0 stores the running scores.  Once
+            // the position is a multiple of four the scores move in 16-byte LDS accesses, in blocks of 16 with three
+            // register sets in rotation: a block is requested two blocks (32 dependent adds) before its first add, which
+            // covers the LDS latency of a compute unit whose other owners are sorting.  (The run length is used by all
+            // lanes on purpose: with the chain under `if (lane == 0)` the compiler moves the ballots above into that
+            // branch, and the wave never leaves it.)
+            {
+                const bool wr = lane == 0;
+                float acc = __uint_as_float(L.s.px[s]);
+                const float *cs = L.s.pc + s;
+                float *ws = reinterpret_cast<float *>(L.s.px) + s;
+                int j = 0;
+                const int peel = min(r, (4 - (s & 3)) & 3);
+                for (; j < peel; ++j) { acc += cs[j]; if (wr) ws[j] = acc; }
+                const int nblk = (r - j) >> 4;
+                const float4 *c4 = reinterpret_cast<const float4 *>(cs + j);
+                float4 *w4 = reinterpret_cast<float4 *>(ws + j);
+                auto load = [&](float4 (&q)[4], int blk) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q[k] = c4[4 * blk + k];
+                };
+                auto proc = [&](const float4 (&q)[4], int blk) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float w0 = acc + q[k].x, w1 = w0 + q[k].y, w2 = w1 + q[k].z, w3 = w2 + q[k].w;
+                        acc = w3;
+                        if (wr) w4[4 * blk + k] = make_float4(w0, w1, w2, w3);
+                    }
+                };
+                float4 qa[4], qb[4], qc[4];
+                if (nblk > 0) load(qa, 0);
+                if (nblk > 1) load(qb, 1);
+                for (int blk = 0; blk < nblk; blk += 3) {
+                    if (blk + 2 < nblk) load(qc, blk + 2);
+                    proc(qa, blk);
+                    if (blk + 3 < nblk) load(qa, blk + 3);
+                    if (blk + 1 < nblk) proc(qb, blk + 1);
+                    if (blk + 4 < nblk) load(qb, blk + 4);
+                    if (blk + 2 < nblk) proc(qc, blk + 2);
                 }
-                const float w0 = acc + n0, w1 = w0 + n1, w2 = w1 + n2, w3 = w2 + n3, w4 = w3 + n4, w5 = w4 + n5, w6 = w5 + n6, w7 = w6 + n7;
-                acc = w7;
-                put8(j, w0, w1, w2, w3, w4, w5, w6, w7);
-                j += 8;
+                j += nblk << 4;
+                for (; j < r; ++j) { acc += cs[j]; if (wr) ws[j] = acc; }
+                if (wr) fin[s] = make_int2((b0 + (int)(bs >> 2)) * 4 + (int)(bs & 3u), __float_as_int(acc));
             }
-            for (; j < r; ++j) {
-                acc += cs[j];
-                ws[j] = __float_as_uint(acc);
+        }
+        for (int row = row0; row >= 0 && row < rows; row += row_step) {
+            const int s = row * 64 + lane;
+            if (s >= total) continue;
+            const uint32_t bs = L.s.sg[s];
+            const bool head = s == 0 || L.s.sg[s - 1] != bs;
+            if (!head || (L.s.po[s] & 2)) continue;
+            const int bucket = b0 + (int)(bs >> 2), slot = (int)(bs & 3u);
+            float acc = __uint_as_float(L.s.px[s]);
+            int e = s;
+            for (;;) {
+                // items e .. e + 3 (reads past the end of the run, or of the partition, are not used)
+                const float c0 = L.s.pc[e], c1 = L.s.pc[min(e + 1, CAP - 1)], c2 = L.s.pc[min(e + 2, CAP - 1)], c3 = L.s.pc[min(e + 3, CAP - 1)];
+                const uint8_t k0 = L.s.po[e], k1 = L.s.po[min(e + 1, CAP - 1)], k2 = L.s.po[min(e + 2, CAP - 1)], k3 = L.s.po[min(e + 3, CAP - 1)];
+                acc += c0; L.s.px[e] = __float_as_uint(acc);
+                if (!(k0 & 1)) break;
+                acc += c1; L.s.px[e + 1] = __float_as_uint(acc);
+                if (!(k1 & 1)) break;
+                acc += c2; L.s.px[e + 2] = __float_as_uint(acc);
+                if (!(k2 & 1)) break;
+                acc += c3; L.s.px[e + 3] = __float_as_uint(acc);
+                if (!(k3 & 1)) break;
+                e += 4;
             }
-            if (lane == 0) fin[s] = make_int2(bucket * 4 + slot, __float_as_int(acc));
+            fin[s] = make_int2(bucket * 4 + slot, __float_as_int(acc));
         }
     }
     __syncthreads();
@@ -1517,7 +1548,7 @@ struct HotArgs {
 };
 
 template <int CAP>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CAP <= 1024 ? 8 : 1, 8))) k_round1(Geo g, MainArgs MA, LruArgs LA, HotArgs HA, Score sc) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CAP <= kCapSmall ? 6 : 1, 8))) k_round1(Geo g, MainArgs MA, LruArgs LA, HotArgs HA, Score sc) {
     CAFE_KWIN(3);
     __shared__ __attribute__((aligned(16))) OwnerLds<CAP, false> L;
     __shared__ int heavy[kMaxHeavy];
@@ -2092,7 +2123,7 @@ static int pick_cap(cafe_sketch *s, int n) {
     long big = 0;
     for (int i = 0; i < 32; ++i) big = std::max(big, (long)s->cap_hist[i]);
     if (m->st.fallback) return 8192;
-    if (big + big / 8 + 32 <= 1024) return 1024;
+    if (big + big / 8 + 32 <= kCapSmall) return kCapSmall;
     if (big + big / 8 + 32 <= 2048) return 2048;
     return 8192;
 }
@@ -2197,8 +2228,8 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     // form (40 KB LDS), one of the <8192> form.
     const uint32_t mv = s->last_moves;
     const int fix_grid = mv <= 256 ? kFixGrid : cap == 8192 ? 256 : 512;
-    if (cap == 1024) {
-        hipLaunchKernelGGL((k_round1<1024>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
+    if (cap == kCapSmall) {
+        hipLaunchKernelGGL((k_round1<kCapSmall>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
         hipLaunchKernelGGL((k_fix<2048>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
     } else if (cap == 2048) {
         hipLaunchKernelGGL((k_round1<2048>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);

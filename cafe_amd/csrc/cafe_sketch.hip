@@ -419,7 +419,7 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
     else if (!strcmp(name, "plan_ahead")) s->opt_plan_ahead = value ? 1 : 0;
     else if (!strcmp(name, "move_cap")) s->opt_move_cap = value;
     else if (!strcmp(name, "ids_ready")) s->opt_ids_ready = value ? 1 : 0;
-    else if (!strcmp(name, "owner_cap")) s->force_cap = value == 1024 || value == 2048 || value == 8192 ? value : 0;
+    else if (!strcmp(name, "owner_cap")) s->force_cap = value == 1024 || value == 1536 ? 1536 : value == 2048 || value == 8192 ? value : 0;     // 1536 = kCapSmall (cafe_insert_par.hip)
     else if (!strcmp(name, "overlap")) s->opt_overlap = value;
     else if (!strcmp(name, "fuse_fields")) s->opt_fuse_fields = value ? 1 : 0;
     else if (!strcmp(name, "verify")) s->opt_verify = value ? 1 : 0;

@@ -52,6 +52,16 @@ for rid, rn in [(1, "hot"), (2, "lru"), (3, "main C")]:
         for i in o[:3]:
             row = r1[sel][i]
             print("      items", int(tot[sel][i]), "phase ends (us from block start):", [round(float(row[k] - row[0]) / 100.0, 2) if row[k] > 0 else None for k in range(1, 7)])
+ok = (r1[:, 0] > 0) & (r1[:, 6] > 0)
+if ok.any():
+    st = np.sort(r1[ok, 0]); t0 = st[0]
+    ev = np.concatenate([np.stack([r1[ok, 0], np.ones(ok.sum(), np.int64)], 1), np.stack([r1[ok, 6], -np.ones(ok.sum(), np.int64)], 1)])
+    ev = ev[np.argsort(ev[:, 0], kind="stable")]
+    run = np.cumsum(ev[:, 1])
+    print(f"== round1 residency: {ok.sum()} workgroups, most at once {run.max()}, kernel span {(r1[ok, 6].max() - t0) / 100:.2f} us")
+    for t in (1, 2, 4, 8, 12, 16, 20, 24, 28):
+        i = np.searchsorted(ev[:, 0], t0 + t * 100, side="right") - 1
+        print(f"   at {t:2d} us: running {run[i]:5d}   started so far {(st <= t0 + t * 100).sum():5d}")
 show("finish", buf[1], [(1, "scores out"), (2, "flags"), (3, "look-back"), (4, "ranks")])
 show("commit", buf[2], [(1, "verdict"), (2, "partitions"), (3, "ticket"), (4, "close (last)")])
 show("offsets", buf[3], [(1, "column sums"), (2, "prefix+ticket"), (3, "bin scans (last)"), (4, "zero+scalars (last)")])
