@@ -105,6 +105,8 @@ extern "C" int cafe_tables_destroy(cafe_tables_t *t) {
         for (int j = 0; j < 2; ++j)
             if (t->ev_t[k][j]) (void)hipEventDestroy(t->ev_t[k][j]);
     if (t->ev_plan) (void)hipEventDestroy(t->ev_plan);
+    if (t->ev_sums) (void)hipEventDestroy(t->ev_sums);
+    t->ws_bwd_e.release(); t->ws_bwd_f.release();
     (void)hipFree(t->d_w_cold); (void)hipFree(t->d_id_offset); (void)hipFree(t->d_hash_size); (void)hipFree(t->d_cold_base);
     t->ws_norm.release(); t->ws_psum.release(); t->ws_bwd_a.release(); t->ws_bwd_b.release(); t->ws_bwd_c.release(); t->ws_bwd_d.release();
     t->ws_misc.release();
@@ -215,6 +217,10 @@ static int pair_ok(const cafe_sketch_t *s, const cafe_tables_t *t, const char *w
     return 0;
 }
 
+static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,
+                           int batch, int total, float lr, hipStream_t st, hipStream_t pst, int part = 3,
+                           const int32_t *skip_if_2 = nullptr, int gstride = 0);
+
 static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_in_gids,
                           const int32_t *d_fields, int batch, long total_l, int32_t *d_gids, int32_t *d_que, float *d_out,
                           hipStream_t st) {
@@ -257,6 +263,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     // marker packet on `st` between the gather and the norm kernel)
     hipEvent_t fwd_done = s->ev_fwd;
     s->fwd_que = d_que;
+    s->fwd_count++;
 #define CAFE_FWD(L)                                                                                              \
     hipExtLaunchKernelGGL((k_forward<L, false>), dim3(blocks), dim3(256), 0, st, nullptr, fwd_done, 0,           \
                           (const MainBucket *)s->d_main, fm1, (const float *)t->d_w_hot, (float *const *)t->d_w_cold, \
@@ -277,6 +284,15 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     CAFE_HIP_CHECK(hipGetLastError());
     if (plan && !plan_launched) {
         if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream)) return 1;
+    }
+    if (plan && s->opt_split_update && s->low_stream) {
+        // The partition passes of the update that will follow read nothing but this gather's routing: they run right
+        // behind it on the third stream (in a training step: under the dense model's forward and backward), and the
+        // gradient pass of the split update follows them there without a cross-stream hand-over.
+        CAFE_HIP_CHECK(hipStreamWaitEvent(s->low_stream, s->ev_fwd, 0));
+        if (backward_common(t, nullptr, d_que, nullptr, batch, total, 0.f, st, s->low_stream, 17, nullptr, 0)) return 1;
+        t->bwd_plan_que = d_que;
+        t->bwd_plan_fwd = s->fwd_count;
     }
     s->host_us[0] += now_us() - t_begin;
     return 0;
@@ -434,13 +450,14 @@ __global__ void __launch_bounds__(256) k_scale(const float *__restrict__ gn, con
 
 // norms and partial sums of one step: gn [F * batch], psum [F * nparts]
 static int norms_common(cafe_tables_t *t, const float *d_grad_out, int batch, float *gn, float *psum, int *nparts_out,
-                        hipStream_t st) {
+                        hipStream_t st, hipEvent_t done = nullptr) {
     int nparts, rows;
     norm_geometry(batch, &nparts, &rows);
     *nparts_out = nparts;
     if (t->num_fields * batch <= 0) return 0;
     const int lpg = lanes_per_row(t->dim);
-#define CAFE_GN(L) hipLaunchKernelGGL(k_grad_norm<L>, dim3(nparts, t->num_fields), dim3(256), 0, st, d_grad_out, batch, rows, t->dim, gn, psum)
+    // `done`: the kernel's own completion event (no marker packet on st)
+#define CAFE_GN(L) hipExtLaunchKernelGGL(k_grad_norm<L>, dim3(nparts, t->num_fields), dim3(256), 0, st, nullptr, done, 0, d_grad_out, batch, rows, t->dim, gn, psum)
     switch (lpg) {
         case 1: CAFE_GN(1); break;
         case 2: CAFE_GN(2); break;
@@ -657,8 +674,10 @@ __global__ void __launch_bounds__(1024) k_bwd_assign(int Ph, int Pc, const int32
 
 // offsets of the partitions, and the list of (partition, tile) work items: one workgroup per <= kBwdCap pairs
 __global__ void __launch_bounds__(1024) k_bwd_offsets(int Ph, int P, const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off,
-                                                      uint32_t *__restrict__ tiles /* [0] = hot tiles, [1] = all tiles, then (p << 8 | t)... */) {
+                                                      uint32_t *__restrict__ tiles /* [0] = hot tiles, [1] = all tiles, then (p << 8 | t)... */,
+                                                      uint32_t *__restrict__ ecount) {
     CAFE_KWIN(4);
+    if (threadIdx.x == 0 && ecount) *ecount = 0;        // entries of the split update (k_bwd_segments<.., true>)
     __shared__ uint32_t sh[1024], sh2[1024];
     __shared__ uint32_t carry, carry2;
     if (threadIdx.x == 0) { carry = 0; carry2 = 0; }
@@ -737,23 +756,34 @@ extern "C" int cafe_debug_read_bwd(unsigned long long *out) { return hipMemcpyFr
 #define BWD_VAL(k, v) do { } while (0)
 #endif
 
-template <int LPG, int VPL>
+// EMIT: the same walk, but nothing touches the tables: every row's sum goes to sums[entry][dim] and an entry
+// {row key, a lookup of the row, 1 plain / 2 atomic, 0} to entries[entry]; k_bwd_apply does the read-modify-writes later.
+// The sums do not depend on the sketch insert or on the migration, the row updates do (a migrated row is copied before it
+// is updated): split this way the gradient pass runs beside the insert.  Entries live in the partitioned order of the
+// lookups: a tile of n lookups with r rows fills the first r of its n entries (a row's entry is its rank among the
+// tile's rows) and marks the rest empty.  The grid is persistent (workgroup w walks tiles w, w + gridDim.x, ...): it
+// never holds more compute-unit slots than it was given, whatever the number of tiles.
+template <int LPG, int VPL, bool EMIT>
 __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tiles,
                                                       const unsigned long long *__restrict__ items,
                                                       const int32_t *__restrict__ fields, const float *__restrict__ grad,
                                                       float *__restrict__ w_hot, float *const *__restrict__ w_cold,
                                                       const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr,
-                                                      const int32_t *__restrict__ skip_if_2, int gstride) {
+                                                      const int32_t *__restrict__ skip_if_2, int gstride,
+                                                      uint32_t *__restrict__ ecount, uint4 *__restrict__ entries,
+                                                      float4 *__restrict__ sums) {
     CAFE_KWIN(6);
     __shared__ __attribute__((aligned(16))) unsigned long long key[kBwdCap];
     __shared__ float4 bpart[2][VPL][256];      // border partial sums: [0] head of a group's range, [1] tail
     __shared__ int bflag[256];
+    __shared__ uint16_t srank[EMIT ? kBwdCap : 2];     // EMIT: rows that start before sorted position j
+    __shared__ uint32_t wrows[4], s_ebase;
     const int tid = threadIdx.x;
-    const uint32_t tile_at = blockIdx.x;
-    if (tile_at >= tiles[1]) return;
     // queued behind an insert whose verdict the host has not seen yet: if the device rejected it (DevState::fallback
     // == 2) the host issues the step again, and this update with it
     if (skip_if_2 && *skip_if_2 == 2) return;
+    const uint32_t ntiles = tiles[1];
+    for (uint32_t tile_at = blockIdx.x; tile_at < ntiles; tile_at += gridDim.x) {
     // the tile index is kept in 8 bits; a partition with more tiles lets its last workgroup walk the rest
     const uint32_t tl = tiles[2 + tile_at];
     const int p = (int)(tl >> 8), tile = (int)(tl & 255u);
@@ -781,6 +811,21 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
             if (tid < n) key[r] = k;
             __syncthreads();
         }
+        if constexpr (EMIT) {
+            const bool start = tid < n && (tid == 0 || (uint32_t)(key[tid - 1] >> 32) != (uint32_t)(key[tid] >> 32));
+            const unsigned long long m = __ballot(start);
+            const int lane = tid & 63, wave = tid >> 6;
+            if (lane == 0) wrows[wave] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+            for (int w = 0; w < 4; ++w) { const uint32_t c = wrows[w]; all += c; if (w < wave) before += c; }
+            srank[tid] = (uint16_t)(before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+            // the tile's rows take the first `all` of the tile's n entries (entry = position in the partitioned order: no
+            // counter to contend for); the others are marked empty
+            if (tid == 0) s_ebase = o0 + (uint32_t)t0;
+            if (tid >= (int)all && tid < n) entries[o0 + t0 + tid] = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+        }
         BWD_STAMP(1);
         // Each lane group owns a contiguous range of the sorted tile and carries its sum from chunk to chunk.  A row
         // that lies inside one group's range gets its update there.  A row that crosses group borders is summed through
@@ -797,10 +842,13 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
         for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
         int seg_start = rbegin;
         float *lead_row = nullptr;
+        uint32_t lead_slot = 0xffffffffu;
+        const uint32_t ebase = EMIT ? s_ebase : 0u;
         for (int begin = rbegin; begin < rend; begin += kBwdCH) {
             const int end = min(begin + kBwdCH, rend);
-            float4 gr[kBwdCH][VPL], wr[kBwdCH][VPL];
+            float4 gr[kBwdCH][VPL], wr[EMIT ? 1 : kBwdCH][VPL];
             float *rowp[kBwdCH];
+            uint32_t slot_of[kBwdCH];
             unsigned mode = 0;       // per item 3 bits: 0 inside a segment, 1 plain update, 2 atomic update, 3 head partial, 4 tail partial
             int ss = seg_start;
 #pragma unroll
@@ -817,17 +865,23 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                         const bool head = ss == rbegin && head_same, tail = begin + e + 1 == rend && tail_same;
                         m = head ? 3u : tail ? 4u : multi ? 2u : 1u;
                         if (head && tail) m = 5u;                    // the whole range is the middle of one row's run
+                        if constexpr (EMIT) {
+                            // the row starts at ss (in this group's range unless it is a head partial)
+                            slot_of[e] = ebase + srank[ss];
+                            if ((m == 1u || m == 2u || m == 4u) && lig == 0) entries[slot_of[e]] = make_uint4(k, i, (m == 2u || multi) ? 2u : 1u, 0u);
+                        }
                         ss = begin + e + 1;
                     }
                 }
-                rowp[e] = last ? row_ptr(k, i, fields, w_hot, w_cold, cold_base, hotn, batch, dim) : nullptr;
+                if constexpr (!EMIT) rowp[e] = last ? row_ptr(k, i, fields, w_hot, w_cold, cold_base, hotn, batch, dim) : nullptr;
                 mode |= m << (3 * e);
 #pragma unroll
                 for (int v = 0; v < VPL; ++v) {
                     const int c = lig + v * LPG;
                     gr[e][v] = (live && c < dim4) ? g[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    wr[e][v] = (m == 1u && c < dim4) ? reinterpret_cast<const float4 *>(rowp[e])[c]
-                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (!EMIT)
+                        wr[e][v] = (m == 1u && c < dim4) ? reinterpret_cast<const float4 *>(rowp[e])[c]
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             seg_start = ss;
@@ -845,14 +899,17 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                         const int slot = m == 4u ? 1 : 0;
 #pragma unroll
                         for (int v = 0; v < VPL; ++v) bpart[slot][v][tid] = acc[v];
-                        if (m == 4u) lead_row = rowp[e];
+                        if constexpr (EMIT) { if (m == 4u) lead_slot = slot_of[e]; }
+                        else if (m == 4u) lead_row = rowp[e];
                         if (lig == 0) bflag[grp] |= m == 3u ? 1 : m == 4u ? 2 : 5;
                     } else {
 #pragma unroll
                         for (int v = 0; v < VPL; ++v) {
                             const int c = lig + v * LPG;
                             if (c < dim4) {
-                                if (m == 2u) {
+                                if constexpr (EMIT) {
+                                    sums[(size_t)slot_of[e] * dim4 + c] = acc[v];
+                                } else if (m == 2u) {
 #ifndef CAFE_NO_ATOMIC
                                     float *r = rowp[e] + c * 4;
                                     atomicAdd(r + 0, -lr * acc[v].x); atomicAdd(r + 1, -lr * acc[v].y);
@@ -872,7 +929,7 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
             }
         }
         __syncthreads();
-        if (lead_row) {          // uniform over the lane group
+        if (EMIT ? lead_slot != 0xffffffffu : lead_row != nullptr) {          // uniform over the lane group
             float4 sum[VPL];
 #pragma unroll
             for (int v = 0; v < VPL; ++v) sum[v] = bpart[1][v][tid];
@@ -890,7 +947,9 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
             for (int v = 0; v < VPL; ++v) {
                 const int c = lig + v * LPG;
                 if (c < dim4) {
-                    if (multi) {
+                    if constexpr (EMIT) {
+                        sums[(size_t)lead_slot * dim4 + c] = sum[v];
+                    } else if (multi) {
 #ifndef CAFE_NO_ATOMIC
                         float *r = lead_row + c * 4;
                         atomicAdd(r + 0, -lr * sum[v].x); atomicAdd(r + 1, -lr * sum[v].y);
@@ -906,14 +965,94 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
         }
     }
     __syncthreads();
+    }
     BWD_STAMP(2);
 }
 
-// The backward in two parts: 1 the partition passes (they read the routing only) on `pst`, 2 the segment kernel (gradient
-// rows in, table rows updated) on `st`, ordered behind t->ev_plan (recorded here on pst) when the streams differ.
+// Between the two halves of the split update: the non-empty entries, gathered into a list (one counter update per
+// 1024 entries).  list[i] = {row key, a lookup of the row, 1 plain / 2 atomic, entry index = where the row's sum is}.
+__global__ void __launch_bounds__(256) k_bwd_compact(int total, const uint4 *__restrict__ entries, uint32_t *__restrict__ ecount,
+                                                     uint4 *__restrict__ list) {
+    __shared__ uint32_t wcnt[4], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e0 = (blockIdx.x * 256 + tid) * 4;
+    uint4 en[4];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        en[k] = e0 + k < total ? entries[e0 + k] : make_uint4(0u, 0u, 0u, 0u);
+        mine += en[k].z != 0u;
+    }
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wcnt[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (int w = 0; w < 4; ++w) { const uint32_t c = wcnt[w]; all += c; if (w < wave) before += c; }
+    if (tid == 0) s_base = all ? atomicAdd(ecount, all) : 0u;
+    __syncthreads();
+    uint32_t at = s_base + before + inc - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (en[k].z != 0u) { en[k].w = (uint32_t)(e0 + k); list[at++] = en[k]; }
+}
+
+// Second half of the split update: list entry = one table row, W[row] -= lr * sums[entry] (plain read-modify-write;
+// float atomics for the rows of a partition that was walked in several tiles, as in the one-kernel form).  A lane group
+// per row, grid-stride over the *ecount rows of the list.
+template <int LPG, int VPL>
+__global__ void __launch_bounds__(256) k_bwd_apply(const uint32_t *__restrict__ ecount, const uint4 *__restrict__ list,
+                                                   const float4 *__restrict__ sums, const int32_t *__restrict__ fields,
+                                                   float *__restrict__ w_hot, float *const *__restrict__ w_cold,
+                                                   const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr,
+                                                   const int32_t *__restrict__ skip_if_2) {
+    CAFE_KWIN(7);
+    if (skip_if_2 && *skip_if_2 == 2) return;            // see k_bwd_segments
+    constexpr int G = 256 / LPG;
+    const int lig = threadIdx.x % LPG, grp = threadIdx.x / LPG;
+    const int dim4 = dim >> 2;
+    const uint32_t n = *ecount;
+    for (uint32_t i = blockIdx.x * G + grp; i < n; i += gridDim.x * G) {
+        const uint4 en = list[i];
+        float *row = row_ptr(en.x, en.y, fields, w_hot, w_cold, cold_base, hotn, batch, dim);
+        float4 sm[VPL], w[VPL];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int c = lig + v * LPG;
+            sm[v] = c < dim4 ? sums[(size_t)en.w * dim4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            w[v] = (c < dim4 && en.z == 1u) ? reinterpret_cast<const float4 *>(row)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int c = lig + v * LPG;
+            if (c >= dim4) continue;
+            if (en.z == 1u) {
+                w[v].x -= lr * sm[v].x; w[v].y -= lr * sm[v].y; w[v].z -= lr * sm[v].z; w[v].w -= lr * sm[v].w;
+                cafe::store_through16(&reinterpret_cast<float4 *>(row)[c], w[v]);
+            } else {
+#ifndef CAFE_NO_ATOMIC
+                float *r = row + c * 4;
+                atomicAdd(r + 0, -lr * sm[v].x); atomicAdd(r + 1, -lr * sm[v].y);
+                atomicAdd(r + 2, -lr * sm[v].z); atomicAdd(r + 3, -lr * sm[v].w);
+#endif
+            }
+        }
+    }
+}
+
+// The backward in parts (bits of `part`): 1 the partition passes (they read the routing only) on `pst`; 2 the segment
+// kernel (gradient rows in, table rows updated) on `st`, ordered behind t->ev_plan (recorded here on pst) when the
+// streams differ.  The split form of 2, for a step whose sketch insert runs meanwhile: 4 the segment sums (gradient rows
+// in, sums and entries out; tables untouched) on `st`, behind t->ev_plan; 8 the row updates from those sums on `st`,
+// behind t->ev_sums (recorded by part 4 on its stream); 16 with 1: the split form follows (its workspaces are sized and
+// the offsets pass zeroes the entry counter).
 static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,
-                           int batch, int total, float lr, hipStream_t st, hipStream_t pst, int part = 3,
-                           const int32_t *skip_if_2 = nullptr, int gstride = 0) {
+                           int batch, int total, float lr, hipStream_t st, hipStream_t pst, int part,
+                           const int32_t *skip_if_2, int gstride) {
     if (total <= 0) return 0;
     const int64_t rows = (int64_t)t->hotn + t->total_cold_rows;
     if (rows >= (int64_t)0xFFFFFFFFLL) { set_error("cafe_backward_sgd_dev: more than 2^32 table rows"); return 1; }
@@ -929,46 +1068,95 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     if (t->ws_bwd_b.reserve(4 * (size_t)kBwdMaxBins + 16) || t->ws_misc.reserve(4 * (size_t)max_tiles + 32) ||
         t->ws_bwd_c.reserve(8 * (size_t)total) ||
         t->ws_bwd_d.reserve(8 * (size_t)total)) return 1;
+    if ((part & 28) && (t->ws_bwd_e.reserve(32 * (size_t)total + 64) || t->ws_bwd_f.reserve(4 * (size_t)total * t->dim + 64))) return 1;
     uint32_t *cnt = t->ws_bwd_a.as<uint32_t>(), *off = t->ws_bwd_b.as<uint32_t>();
     uint32_t *rank = t->ws_bwd_c.as<uint32_t>(), *keys = rank + total;
     unsigned long long *items = t->ws_bwd_d.as<unsigned long long>();
     uint32_t *tiles = t->ws_misc.as<uint32_t>();
+    // split form: [0] the entry counter (zeroed by the offsets pass of every step), entries from byte 64
+    uint32_t *ecount = t->ws_bwd_e.p ? t->ws_bwd_e.as<uint32_t>() : nullptr;
+    uint4 *entries = ecount ? reinterpret_cast<uint4 *>(ecount + 16) : nullptr, *elist = entries ? entries + total : nullptr;
+    float4 *sums = t->ws_bwd_f.p ? t->ws_bwd_f.as<float4>() : nullptr;
     if (part & 1) {
         hipLaunchKernelGGL(k_bwd_assign, dim3((total + kBwdChunk - 1) / kBwdChunk), dim3(1024), 4 * (size_t)P, pst, Ph, Pc, d_fields,
                            d_que, t->d_hash_size, t->d_cold_base, t->hotn, batch, total, cnt, rank, keys);
-        hipLaunchKernelGGL(k_bwd_offsets, dim3(1), dim3(1024), 0, pst, Ph, P, cnt, off, tiles);
+        hipLaunchKernelGGL(k_bwd_offsets, dim3(1), dim3(1024), 0, pst, Ph, P, cnt, off, tiles, ecount);
         hipLaunchKernelGGL(k_bwd_scatter, dim3((std::max(total, P) + 255) / 256), dim3(256), 0, pst, Ph, Pc, t->hotn, total, keys, rank, off,
                            cnt, items);
-        if (pst != st) {
+        if (pst != st || (part & 4)) {
             if (!t->ev_plan) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_plan, kDeviceEvent));
             CAFE_HIP_CHECK(hipEventRecord(t->ev_plan, pst));
         }
     }
-    if (!(part & 2)) { CAFE_HIP_CHECK(hipGetLastError()); return 0; }
-    if (pst != st) CAFE_HIP_CHECK(hipStreamWaitEvent(st, t->ev_plan, 0));
+    if (!(part & 14)) { CAFE_HIP_CHECK(hipGetLastError()); return 0; }
     const int grid = max_tiles;
-#define CAFE_SEG(L, V)                                                                                                   \
-    hipLaunchKernelGGL((k_bwd_segments<L, V>), dim3(grid), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
-                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_if_2, gstride ? gstride : t->dim)
-    const int tk = 1;
-    if (t->timing) (void)hipEventRecord(t->ev_t[tk][0], st);
-    if (vpl == 1) {
-        switch (lpg) {
-            case 1: CAFE_SEG(1, 1); break;
-            case 2: CAFE_SEG(2, 1); break;
-            case 4: CAFE_SEG(4, 1); break;
-            case 8: CAFE_SEG(8, 1); break;
-            case 16: CAFE_SEG(16, 1); break;
-            case 32: CAFE_SEG(32, 1); break;
-            default: CAFE_SEG(64, 1); break;
-        }
-    } else if (vpl == 2) {
-        CAFE_SEG(64, 2);
-    } else {
-        CAFE_SEG(64, 4);
+    const int gs = gstride ? gstride : t->dim;
+    // the gradient pass of the split form shares the device with the insert's kernels: a persistent grid of six
+    // workgroups per compute unit (1024 .. 2560 measured within 1 % of each other on cfg3)
+    static const int emit_grid = getenv("CAFE_EMIT_GRID") ? atoi(getenv("CAFE_EMIT_GRID")) : 1536;
+#define CAFE_SEG(L, V, E)                                                                                                \
+    hipLaunchKernelGGL((k_bwd_segments<L, V, E>), dim3(E ? std::min(grid, emit_grid) : grid), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
+                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_if_2, gs, ecount, entries, sums)
+#define CAFE_SEG_ALL(E)                                                                                                  \
+    if (vpl == 1) {                                                                                                      \
+        switch (lpg) {                                                                                                   \
+            case 1: CAFE_SEG(1, 1, E); break;                                                                            \
+            case 2: CAFE_SEG(2, 1, E); break;                                                                            \
+            case 4: CAFE_SEG(4, 1, E); break;                                                                            \
+            case 8: CAFE_SEG(8, 1, E); break;                                                                            \
+            case 16: CAFE_SEG(16, 1, E); break;                                                                          \
+            case 32: CAFE_SEG(32, 1, E); break;                                                                          \
+            default: CAFE_SEG(64, 1, E); break;                                                                          \
+        }                                                                                                                \
+    } else if (vpl == 2) {                                                                                               \
+        CAFE_SEG(64, 2, E);                                                                                              \
+    } else {                                                                                                             \
+        CAFE_SEG(64, 4, E);                                                                                              \
     }
+    if (part & 2) {
+        if (pst != st) CAFE_HIP_CHECK(hipStreamWaitEvent(st, t->ev_plan, 0));
+        if (t->timing) (void)hipEventRecord(t->ev_t[1][0], st);
+        CAFE_SEG_ALL(false)
+        if (t->timing) (void)hipEventRecord(t->ev_t[1][1], st);
+    }
+    if (part & 4) {
+        if (pst != st) CAFE_HIP_CHECK(hipStreamWaitEvent(st, t->ev_plan, 0));
+        if (t->timing) (void)hipEventRecord(t->ev_t[1][0], st);
+        CAFE_SEG_ALL(true)
+        hipLaunchKernelGGL(k_bwd_compact, dim3((total + 1023) / 1024), dim3(256), 0, st, total, entries, ecount, elist);
+        if (t->timing) (void)hipEventRecord(t->ev_t[1][1], st);
+        if (!t->ev_sums) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_sums, kDeviceEvent));
+        CAFE_HIP_CHECK(hipEventRecord(t->ev_sums, st));
+    }
+#undef CAFE_SEG_ALL
 #undef CAFE_SEG
-    if (t->timing) (void)hipEventRecord(t->ev_t[tk][1], st);
+    if (part & 8) {
+        if (pst != st) CAFE_HIP_CHECK(hipStreamWaitEvent(st, t->ev_sums, 0));
+        // a lane group per row; the rows of a step are at most its lookups, usually a fraction of them
+        const int G = 256 / lpg;
+        const int agrid = std::max(1, std::min((total + G - 1) / G, 4096));
+        if (t->timing) (void)hipEventRecord(t->ev_t[4][0], st);
+#define CAFE_APPLY(L, V)                                                                                                 \
+    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, d_fields, t->d_w_hot, t->d_w_cold, \
+                       t->d_cold_base, t->hotn, batch, t->dim, lr, skip_if_2)
+        if (vpl == 1) {
+            switch (lpg) {
+                case 1: CAFE_APPLY(1, 1); break;
+                case 2: CAFE_APPLY(2, 1); break;
+                case 4: CAFE_APPLY(4, 1); break;
+                case 8: CAFE_APPLY(8, 1); break;
+                case 16: CAFE_APPLY(16, 1); break;
+                case 32: CAFE_APPLY(32, 1); break;
+                default: CAFE_APPLY(64, 1); break;
+            }
+        } else if (vpl == 2) {
+            CAFE_APPLY(64, 2);
+        } else {
+            CAFE_APPLY(64, 4);
+        }
+#undef CAFE_APPLY
+        if (t->timing) (void)hipEventRecord(t->ev_t[4][1], st);
+    }
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1044,7 +1232,9 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
         float *gn = t->ws_norm.as<float>(), *psum = gn + total;
         const double decay0 = s->decay;
         const int batch_num0 = s->batch_num;
-        bool plan_done = false;
+        bool plan_done = false, sums_done = false;
+        // the update in two kernels when there is a stream to run the first of them beside the insert
+        const bool split = side != st && s->opt_split_update && s->low_stream;
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (side != st) {
                 // the second stream continues behind the forward that produced this routing (its own completion event),
@@ -1057,10 +1247,19 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
                 }
             }
             int nparts = 0;
+            // the partition passes were made behind the forward that wrote this routing (cafe_forward_dev)
+            const bool early = split && attempt == 0 && s->fwd_que == d_que && t->bwd_plan_que == d_que && t->bwd_plan_fwd == s->fwd_count;
+            if (early) plan_done = true;
             if (attempt == 0) {
                 if (t->timing) (void)hipEventRecord(t->ev_t[3][0], st);
-                if (norms_common(t, d_grad_out, batch, gn, psum, &nparts, st)) return 1;
+                if (norms_common(t, d_grad_out, batch, gn, psum, &nparts, st, split ? s->ev_gn : nullptr)) return 1;
                 if (t->timing) (void)hipEventRecord(t->ev_t[3][1], st);
+                if (early) {
+                    // the gradient pass behind them, once the norm kernel (which read the same gradient) is complete
+                    CAFE_HIP_CHECK(hipStreamWaitEvent(s->low_stream, s->ev_gn, 0));
+                    if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, s->low_stream, s->low_stream, 4)) return 1;
+                    sums_done = true;
+                }
             } else {
                 int rows;
                 norm_geometry(batch, &nparts, &rows);
@@ -1079,18 +1278,47 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
                 // the partition passes of the update (they read the routing only) beside the insert.  (The update itself
                 // stays behind the migration: run beside the insert it slowed the insert's latency-bound kernels by
                 // more than it saved, and hot rows are not disjoint from migration targets after a reset.)
-                if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 1)) return 1;
+                if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, split ? 17 : 1)) return 1;
                 plan_done = true;
+                if (split) {
+                    // The gradient pass (segment sums; tables untouched) on the low-priority stream: behind the norm
+                    // kernel (which read the same gradient: it is complete) and the partition passes.  It runs while the
+                    // insert's latency-bound kernels leave the memory system idle; the row updates follow the migration.
+                    CAFE_HIP_CHECK(hipStreamWaitEvent(s->low_stream, s->ev_gn, 0));
+                    if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, s->low_stream, side, 4)) return 1;
+                    sums_done = true;
+                }
             }
             if (migrate_list(s, t, d_local_ids, d_gids, d_ins, batch, st)) return 1;
-            if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, plan_done ? side : st, plan_done ? 2 : 3,
-                                &s->d_state->fallback)) return 1;
+            if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, sums_done ? s->low_stream : plan_done ? side : st,
+                                sums_done ? 8 : plan_done ? 2 : 3, &s->d_state->fallback)) return 1;
             bool rejected = false;
             int reason = 0;
             const double t_wait = now_us();
             if (cafe::last_insert_verdict(s, &rejected, &reason)) return 1;
             s->host_us[1] += t_wait - t_begin; s->host_us[2] += now_us() - t_wait; s->host_us[3] += 1;
-            if (!rejected) { s->force_cap_once = 0; return 0; }
+            if (!rejected) {
+                s->force_cap_once = 0;
+                if (getenv("CAFE_DEBUG_SYNC")) {
+                    const double t_dbg = now_us();
+                    for (;;) {
+                        const hipError_t a = hipStreamQuery(st), b = s->low_stream ? hipStreamQuery(s->low_stream) : hipSuccess;
+                        if (a == hipSuccess && b == hipSuccess) break;
+                        if (now_us() - t_dbg > 10e6) {
+                            auto name = [](hipError_t e) { return e == hipSuccess ? "done" : e == hipErrorNotReady ? "busy" : "error"; };
+                            FILE *dbg = fopen("gpurun_out/cafe_stuck.txt", "w");
+                            if (!dbg) dbg = stderr;
+                            fprintf(dbg, "[cafe] step %u stuck: st %s low %s side %s | ev_gn %s ev_fwd %s t.ev_plan %s t.ev_sums %s | split %d sums_done %d plan_done %d\n",
+                                    s->call_seq, name(a), name(b), name(hipStreamQuery(s->side_stream)), name(hipEventQuery(s->ev_gn)),
+                                    name(hipEventQuery(s->ev_fwd)), t->ev_plan ? name(hipEventQuery(t->ev_plan)) : "-",
+                                    t->ev_sums ? name(hipEventQuery(t->ev_sums)) : "-", (int)split, (int)sums_done, (int)plan_done);
+                            fflush(dbg);
+                            abort();
+                        }
+                    }
+                }
+                return 0;
+            }
             if (reason == 4) s->inner_reset_rejects++;
             // nothing was applied on the device: take the call counters back as well
             s->decay = decay0;
@@ -1109,7 +1337,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             if (cafe_insert_dev(s, d_gids + o, d_scores + o, nn, d_ins + o, stream)) return 1;
             if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, cadence ? f : 0, cadence ? 1 : F, stream)) return 1;
         }
-        return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, 2);
+        return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, sums_done ? s->low_stream : side, sums_done ? 8 : 2);
     }
     if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
     for (int f = 0; f < (cadence ? F : 1); ++f) {

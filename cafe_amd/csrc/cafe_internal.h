@@ -68,6 +68,11 @@ struct cafe_sketch {
     // partition offsets, item records) and the partition passes of the backward run there, beside the score kernel on
     // the caller's stream (cafe_backward_update_dev).
     hipStream_t side_stream = nullptr;
+    // Third stream, lowest priority: the gradient pass of the split update (segment sums) beside the insert's kernels
+    hipStream_t low_stream = nullptr;
+    hipEvent_t ev_gn = nullptr;         // completion of the norm kernel (it read the gradient: the gradient is ready)
+    int opt_split_update = 1;
+    uint64_t fwd_count = 0;             // gathers issued (cafe_tables::bwd_plan_fwd names the one its partition passes belong to)
     int opt_overlap = 3;
     hipEvent_t ev_head_fork = nullptr, ev_head_join = nullptr;
     hipEvent_t ev_plan = nullptr;       // plan made beside the forward (cafe_forward_dev) is complete
@@ -112,13 +117,16 @@ struct cafe_tables {
     int32_t *d_hash_size = nullptr;  // device array [F]
     int64_t *d_cold_base = nullptr;  // device array [F+1]: first row of field f in the unified cold row space
     int64_t total_cold_rows = 0;
-    cafe::DevBuf ws_norm, ws_psum, ws_bwd_a, ws_bwd_b, ws_bwd_c, ws_bwd_d, ws_misc;
+    cafe::DevBuf ws_norm, ws_psum, ws_bwd_a, ws_bwd_b, ws_bwd_c, ws_bwd_d, ws_bwd_e, ws_bwd_f, ws_misc;
     // optional HIP-event timing (bench.py's roofline figures): [0] k_forward, [1] k_bwd_segments, [2] the sketch insert
     // (round 1 .. commit), [3] k_grad_norm
     int timing = 0;
     // [4] the hot-table half of k_bwd_segments when it runs on the second stream
     hipEvent_t ev_t[5][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     hipEvent_t ev_plan = nullptr;    // partition passes of the backward done (recorded on the sketch's side stream)
+    const void *bwd_plan_que = nullptr; // routing array the partition passes queued by the last gather read
+    uint64_t bwd_plan_fwd = 0;
+    hipEvent_t ev_sums = nullptr;    // segment sums of the split update done (recorded on the sketch's low-priority stream)
 };
 
 namespace cafe {

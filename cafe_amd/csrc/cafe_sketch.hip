@@ -375,12 +375,20 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
         int prio_least = 0, prio_most = 0;
         CAFE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_most));
         CAFE_HIP_CHECK(hipStreamCreateWithPriority(&s->side_stream, hipStreamNonBlocking, prio_most));
+        // The third one carries a bandwidth kernel beside the insert's short kernels.  Default priority, not the lowest:
+        // the caller's stream waits for this one (the row updates wait for the segment sums), and in a process that
+        // holds more queues than the hardware schedules at once a lowest-priority queue was never scheduled while the
+        // waiting queue counted as busy (a full test session hung at the first step of its 29th test).
+        (void)prio_least;
+        CAFE_HIP_CHECK(hipStreamCreateWithPriority(&s->low_stream, hipStreamNonBlocking, 0));
     }
     if (const char *e = getenv("CAFE_OVERLAP")) s->opt_overlap = atoi(e);
+    if (const char *e = getenv("CAFE_SPLIT_UPDATE")) s->opt_split_update = atoi(e);
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_fork, kDeviceEvent));
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_join, kDeviceEvent));
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_plan, kDeviceEvent));
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fwd, kDeviceEvent));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_gn, kDeviceEvent));
     if (s->ws_misc.reserve(4096)) return 1;
     CAFE_HIP_CHECK(hipMemset(s->d_main, 0, sizeof(MainBucket) * (size_t)s->n1));
     CAFE_HIP_CHECK(hipMemset(s->d_lru, 0, sizeof(LruBucket) * (size_t)s->n2));
@@ -399,6 +407,8 @@ extern "C" int cafe_sketch_destroy(cafe_sketch_t *s) {
     (void)hipFree(s->d_main); (void)hipFree(s->d_lru); (void)hipFree(s->d_fifo); (void)hipFree(s->d_state);
     if (s->h_pinned) (void)hipHostFree(s->h_pinned);
     if (s->side_stream) (void)hipStreamDestroy(s->side_stream);
+    if (s->low_stream) (void)hipStreamDestroy(s->low_stream);
+    if (s->ev_gn) (void)hipEventDestroy(s->ev_gn);
     if (s->ev_head_fork) (void)hipEventDestroy(s->ev_head_fork);
     if (s->ev_head_join) (void)hipEventDestroy(s->ev_head_join);
     if (s->ev_plan) (void)hipEventDestroy(s->ev_plan);
@@ -419,6 +429,7 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
     else if (!strcmp(name, "plan_ahead")) s->opt_plan_ahead = value ? 1 : 0;
     else if (!strcmp(name, "move_cap")) s->opt_move_cap = value;
     else if (!strcmp(name, "ids_ready")) s->opt_ids_ready = value ? 1 : 0;
+    else if (!strcmp(name, "split_update")) s->opt_split_update = value;
     else if (!strcmp(name, "owner_cap")) s->force_cap = value == 1024 || value == 1536 ? 1536 : value == 2048 || value == 8192 ? value : 0;     // 1536 = kCapSmall (cafe_insert_par.hip)
     else if (!strcmp(name, "overlap")) s->opt_overlap = value;
     else if (!strcmp(name, "fuse_fields")) s->opt_fuse_fields = value ? 1 : 0;
@@ -756,7 +767,26 @@ static int wait_last(cafe_sketch *s, Mirror *m) {
         __builtin_ia32_pause();
         if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
-    if (!seen) CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));
+    if (!seen) {
+        // a step that does not come back within ten seconds is reported once, with what each stream of the handle is
+        // doing, before the wait goes on
+        for (;;) {
+            const hipError_t q = hipStreamQuery(s->last_stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) CAFE_HIP_CHECK(q);
+            if (*seqp == s->call_seq) break;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+                auto name = [](hipError_t e) { return e == hipSuccess ? "done" : e == hipErrorNotReady ? "busy" : "error"; };
+                fprintf(stderr, "[cafe] call %u: no verdict after 10 s (snapshot %u): caller's stream %s, second stream %s, third stream %s; "
+                        "events: plan %s, forward %s, norms %s\n", s->call_seq, *seqp, name(q),
+                        s->side_stream ? name(hipStreamQuery(s->side_stream)) : "-", s->low_stream ? name(hipStreamQuery(s->low_stream)) : "-",
+                        name(hipEventQuery(s->ev_plan)), name(hipEventQuery(s->ev_fwd)), s->ev_gn ? name(hipEventQuery(s->ev_gn)) : "-");
+                CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+    }
     read_mirror(s, m);
     if (m->seq != s->call_seq) { set_error("internal: state snapshot %u does not belong to call %u", m->seq, s->call_seq); return 1; }
     take_snapshot(s, *m);

@@ -240,17 +240,20 @@ def test_crossing_burst_fires_the_reset_at_an_inner_field_boundary(oracle_mod):
         _run_steps(coll, cpu, oracle_mod, *[[x] for x in batch(5)])
 
 
+@pytest.mark.parametrize("B", [2048, 8192], ids=["one_stream", "split_update"])
 @pytest.mark.parametrize("option,value,reason,hotn", [
     ("max_rounds", 1, "rounds_not_settled", 1200),
     ("move_cap", 1, "workspace_limit", 1200),
     (None, 0, "free_list", 150),
 ], ids=["rounds", "move_list", "free_list"])
-def test_fused_steps_that_the_device_rejects_stay_exact(option, value, reason, hotn, oracle_mod):
+def test_fused_steps_that_the_device_rejects_stay_exact(option, value, reason, hotn, B, oracle_mod):
     """every reason for leaving the parallel path, forced inside fused steps (the device rejects the
     step before applying anything; the host issues it again with the largest owners, then call by call): too few
-    rounds enqueued, the move list of a main partition full, the free list running dry inside the batch."""
+    rounds enqueued, the move list of a main partition full, the free list running dry inside the batch.  B = 8192
+    (32768 lookups) is the size from which a step uses the handle's other streams: the update is then split (segment sums
+    beside the insert, row updates behind the migration) and a rejected step re-queues only the row updates."""
     from cafe_amd.collection import CafeEmbeddingCollection
-    F, B, dim, thr = 4, 2048, 16, 2
+    F, dim, thr = 4, 16, 2
     counts = [40000, 9000, 70000, 3000]
     hash_sizes = [211, 37, 499, 13]
     coll = CafeEmbeddingCollection(counts, dim, hotn, hash_sizes, threshold=thr, adjust_thres=1, alpha=1.0000005, seed=6)
