@@ -253,24 +253,29 @@ def main():
     dt = windows[len(windows) // 2] if reps % 2 else 0.5 * (windows[reps // 2 - 1] + windows[reps // 2])
 
     # roofline: the library records HIP events around its kernels on the stream they are launched on (timing mode);
-    # measured in a few extra steps behind the timed region.  [0] k_forward, [1] k_bwd_segments, [2] the insert chain
-    # (k_round1 .. k_commit), [3] k_grad_norm
+    # measured in a few extra steps behind the timed region.  [0] k_forward, [1] k_bwd_segments (+ k_bwd_compact), [2] the
+    # insert chain (k_round1 .. k_commit), [3] k_grad_norm, [4] k_bwd_apply (the second kernel of the update when a step
+    # runs it in two: the segment sums on the library's third stream beside the insert, the row updates behind the
+    # migration; [1] + [4] is then the update's launch time)
     import ctypes
     coll = eng if world == 1 else eng.backend.coll
     L = coll.L
     kern = None
     if world == 1:
         L.cafe_tables_set_timing(coll.tables, 1)
-        acc = [0.0, 0.0, 0.0, 0.0]
+        acc = [0.0, 0.0, 0.0, 0.0, 0.0]
         kreps = 20
         ms = ctypes.c_float()
         for _ in range(kreps):
             step(it); it += 1
-            for k in range(4):
-                L.cafe_tables_kernel_ms(coll.tables, k, ctypes.byref(ms))
-                acc[k] += ms.value
+            for k in range(5):
+                if L.cafe_tables_kernel_ms(coll.tables, k, ctypes.byref(ms)) == 0:      # [4] only exists for split updates
+                    acc[k] += ms.value
         L.cafe_tables_set_timing(coll.tables, 0)
         kern = [a / kreps for a in acc]
+        split_update = kern[4] > 0
+        update_parts = {"k_bwd_segments_us": round(kern[1] * 1e3, 2), "k_bwd_apply_us": round(kern[4] * 1e3, 2)}
+        kern[1] += kern[4]
     per_gpu = None
     if world > 1:
         # every rank times the two bandwidth kernels of its shard (the lookups routed to it); gathered on rank 0
@@ -298,7 +303,9 @@ def main():
         #   k_bwd_segments   output gradient 4D + table row read-modify-write 8D
         #   insert chain     104: id 4, score 4, main bucket 64 read + write back 32 (k_round1 .. k_commit)
         #   k_grad_norm      output gradient 4D + norm 4: a SECOND read of the gradient, outside the 160 + 20 D minimum
-        names = ["k_forward (fused sketch query + hot/cold row gather)", "k_bwd_segments (segment sums + SGD row update)",
+        names = ["k_forward (fused sketch query + hot/cold row gather)",
+                 "k_bwd_segments + k_bwd_apply (segment sums beside the insert, then SGD row updates)" if world == 1 and split_update
+                 else "k_bwd_segments (segment sums + SGD row update)",
                  "insert chain (k_round1, k_fix, k_finish, k_commit)", "k_grad_norm (scores, one pass over the gradient)"]
         per_lookup = [56 + 8 * D, 12 * D, 104, 4 * D + 4]
         roof = None
@@ -315,6 +322,8 @@ def main():
                         "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tj.get(names[k].split(" ")[0])}
             dom = 0 if kern[0] >= kern[1] else 1
             e = entry(dom)
+            if dom == 1 and split_update:
+                e["kernel"] += f" {update_parts}"
             roof = {"bound": "hbm", "kernel": e["kernel"], "achieved": e["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": e["frac"], "traffic": e["traffic"], "avg_launch_us": e["avg_launch_us"],
                     "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],

@@ -88,7 +88,14 @@ extern "C" int cafe_tables_set_timing(cafe_tables_t *t, int on) {
 extern "C" int cafe_tables_kernel_ms(cafe_tables_t *t, int which, float *ms) {
     if (which < 0 || which > 4 || !t->ev_t[which][0]) { set_error("cafe_tables_kernel_ms: timing was not enabled"); return 1; }
     CAFE_HIP_CHECK(hipEventSynchronize(t->ev_t[which][1]));
-    CAFE_HIP_CHECK(hipEventElapsedTime(ms, t->ev_t[which][0], t->ev_t[which][1]));
+    const hipError_t e = hipEventElapsedTime(ms, t->ev_t[which][0], t->ev_t[which][1]);
+    if (e != hipSuccess) {
+        // a pair that no step has recorded (the second kernel of the update when updates run as one kernel): not an error
+        // of the device, and it must not stay behind as HIP's last error
+        (void)hipGetLastError();
+        set_error("cafe_tables_kernel_ms: timer %d was not recorded", which);
+        return 1;
+    }
     return 0;
 }
 
@@ -106,6 +113,7 @@ extern "C" int cafe_tables_destroy(cafe_tables_t *t) {
             if (t->ev_t[k][j]) (void)hipEventDestroy(t->ev_t[k][j]);
     if (t->ev_plan) (void)hipEventDestroy(t->ev_plan);
     if (t->ev_sums) (void)hipEventDestroy(t->ev_sums);
+    if (t->h_rows) (void)hipHostFree(t->h_rows);
     t->ws_bwd_e.release(); t->ws_bwd_f.release();
     (void)hipFree(t->d_w_cold); (void)hipFree(t->d_id_offset); (void)hipFree(t->d_hash_size); (void)hipFree(t->d_cold_base);
     t->ws_norm.release(); t->ws_psum.release(); t->ws_bwd_a.release(); t->ws_bwd_b.release(); t->ws_bwd_c.release(); t->ws_bwd_d.release();
@@ -217,6 +225,21 @@ static int pair_ok(const cafe_sketch_t *s, const cafe_tables_t *t, const char *w
     return 0;
 }
 
+// The update in two kernels (segment sums beside the sketch insert, row updates behind the migration) pays when the
+// gradient pass is long enough to be worth hiding and the insert is quiet enough to share the device: measured on
+// MI355X, +5 % (cfg3, 109 MB of gradient per step) and +7 % (218 MB); -4 % at 872 MB (the kernels are long, the overlap
+// buys little and costs the insert its latency), -3 % when the id stream churns (cfg4: the persistent fix-point kernel
+// waits at its grid barrier for workgroups the gradient pass keeps off the compute units), -15 % at D = 16 (14 MB: two
+// extra launches, nothing to hide), -4 % when most lookups hit distinct rows (cfg4: every row's sum is written and read
+// once more, and there are nearly as many rows as lookups; the split form reports rows / lookups, and above 0.4 it is
+// paused for 256 steps).  Evaluated alike by the gather (which queues the partition passes) and the update.
+static bool want_split_update(const cafe_sketch_t *s, const cafe_tables_t *t, int total) {
+    if (!s->opt_split_update || !s->low_stream) return false;
+    if (s->opt_split_update == 2) return true;                   // forced (tests)
+    const double grad_mb = (double)total * t->dim * 4.0 / 1e6;
+    return grad_mb >= 64.0 && grad_mb <= 512.0 && s->last_moves <= 256 && t->split_pause == 0;
+}
+
 static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,
                            int batch, int total, float lr, hipStream_t st, hipStream_t pst, int part = 3,
                            const int32_t *skip_if_2 = nullptr, int gstride = 0);
@@ -285,7 +308,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     if (plan && !plan_launched) {
         if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream)) return 1;
     }
-    if (plan && s->opt_split_update && s->low_stream) {
+    if (plan && want_split_update(s, t, total)) {
         // The partition passes of the update that will follow read nothing but this gather's routing: they run right
         // behind it on the third stream (in a training step: under the dense model's forward and backward), and the
         // gradient pass of the split update follows them there without a cross-stream hand-over.
@@ -1127,6 +1150,8 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         if (t->timing) (void)hipEventRecord(t->ev_t[1][1], st);
         if (!t->ev_sums) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_sums, kDeviceEvent));
         CAFE_HIP_CHECK(hipEventRecord(t->ev_sums, st));
+        if (!t->h_rows) { CAFE_HIP_CHECK(hipHostMalloc((void **)&t->h_rows, 64, hipHostMallocDefault)); t->h_rows[0] = 0; }
+        CAFE_HIP_CHECK(hipMemcpyAsync(t->h_rows, ecount, 4, hipMemcpyDeviceToHost, st));      // read by a later step, never waited for
     }
 #undef CAFE_SEG_ALL
 #undef CAFE_SEG
@@ -1234,7 +1259,13 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
         const int batch_num0 = s->batch_num;
         bool plan_done = false, sums_done = false;
         // the update in two kernels when there is a stream to run the first of them beside the insert
-        const bool split = side != st && s->opt_split_update && s->low_stream;
+        const bool split = side != st && want_split_update(s, t, total);
+        if (split && s->opt_split_update != 2 && t->h_rows && (double)t->h_rows[0] > 0.4 * total) {
+            t->split_pause = 256;            // (this step still runs split: the gather has queued its partition passes)
+            t->h_rows[0] = 0;
+        } else if (!split && t->split_pause > 0) {
+            t->split_pause--;
+        }
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (side != st) {
                 // the second stream continues behind the forward that produced this routing (its own completion event),

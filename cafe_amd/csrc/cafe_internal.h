@@ -126,6 +126,10 @@ struct cafe_tables {
     hipEvent_t ev_plan = nullptr;    // partition passes of the backward done (recorded on the sketch's side stream)
     const void *bwd_plan_que = nullptr; // routing array the partition passes queued by the last gather read
     uint64_t bwd_plan_fwd = 0;
+    // rows / lookups of the last split update that has reported (k_bwd_compact's count, copied to pinned memory): a step
+    // whose lookups mostly hit distinct rows gains nothing from the split (the sums travel through memory once more)
+    uint32_t *h_rows = nullptr;
+    int split_pause = 0;                // steps left before the split form is tried again
     hipEvent_t ev_sums = nullptr;    // segment sums of the split update done (recorded on the sketch's low-priority stream)
 };
 

@@ -38,13 +38,18 @@ def _close(a, b, what, rtol=RTOL, atol=ATOL):
                            f"|a-b| = {np.abs(a - b)[bad].max():.3e}")
 
 
-def test_cfg2_whole_path(oracle_mod):
+@pytest.mark.parametrize("split_update", [1, 2], ids=["update_by_rule", "update_split"])
+def test_cfg2_whole_path(split_update, oracle_mod):
+    """split_update = 2 forces the two-kernel form of the update (segment sums on the library's third stream beside the
+    insert, row updates behind the migration), which the library's own rule reserves for steps with 64 .. 512 MB of
+    gradient (cfg3 / cfg4 shapes; test_cfg4_full_size runs it by rule)."""
     from cafe_amd.collection import CafeEmbeddingCollection
     from cafe_amd.config import workload
     wl = workload("cfg2")
     F, B, D, thr, lr = wl.num_fields, wl.batch, wl.dim, 5, 0.05
     assert (F, B, D) == (26, 8192, 16)
     coll = CafeEmbeddingCollection(wl.counts, D, wl.hotn, wl.hash_sizes, wl.offsets, threshold=thr, alpha=wl.alpha, seed=8)
+    coll.sketch.set_option("split_update", split_update)
     cpu = CpuPipeline(oracle_mod, coll, thr, 1, wl.alpha)
     steps = 30
     ids_all = wl.make_ids(31, steps=steps)

@@ -187,7 +187,8 @@ def _run_steps(coll, cpu, oracle_mod, batches, grads, lr=0.05, check_tables=True
     return deltas
 
 
-def test_crossing_burst_fires_the_reset_at_an_inner_field_boundary(oracle_mod):
+@pytest.mark.parametrize("split_update", [1, 2], ids=["update_by_rule", "update_split"])
+def test_crossing_burst_fires_the_reset_at_an_inner_field_boundary(split_update, oracle_mod):
     """the per-field reset cadence (sketch.cpp:291 at the start of every per-field call) must be
     exact by construction, not by an estimate of the crossing rate.  A quiet stream (a few tens of threshold crossings
     per step) brings real_n close to 1.2 lim; then ONE step brings more than 20 times as many crossings, spread over all
@@ -199,6 +200,7 @@ def test_crossing_burst_fires_the_reset_at_an_inner_field_boundary(oracle_mod):
     counts = [100000] * F
     hash_sizes = [499] * F
     coll = CafeEmbeddingCollection(counts, dim, lim, hash_sizes, threshold=thr, adjust_thres=1, alpha=1.0000005, seed=5)
+    coll.sketch.set_option("split_update", split_update)     # 2: the rejected step re-queues the row updates of a split update
     cpu = _CpuPipeline(oracle_mod, coll, thr, 1, 1.0000005)
     rng = np.random.default_rng(17)
     gen = torch.Generator(device="cuda").manual_seed(2)
@@ -259,6 +261,8 @@ def test_fused_steps_that_the_device_rejects_stay_exact(option, value, reason, h
     coll = CafeEmbeddingCollection(counts, dim, hotn, hash_sizes, threshold=thr, adjust_thres=1, alpha=1.0000005, seed=6)
     if option:
         coll.sketch.set_option(option, value)
+    if B == 8192:
+        coll.sketch.set_option("split_update", 2)        # forced: the library's rule wants 64 MB of gradient per step
     cpu = _CpuPipeline(oracle_mod, coll, thr, 1, 1.0000005)
     rng = np.random.default_rng(23)
     gen = torch.Generator(device="cuda").manual_seed(3)

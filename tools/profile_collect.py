@@ -69,8 +69,21 @@ for k in ("k_forward", "k_bwd_segments", "k_grad_norm"):
     fk, wk = pick(fetch, k), pick(write, k)
     if fk is None or wk is None:
         continue
+    parts = None
+    if k == "k_bwd_segments" and pick(fetch, "k_bwd_apply") is not None:
+        # the update in two kernels (+ the compaction of the row list between them): their traffic is the update's
+        parts = {}
+        for extra in ("k_bwd_compact", "k_bwd_apply"):
+            fe, we = pick(fetch, extra), pick(write, extra)
+            if fe is None or we is None:
+                continue
+            parts[extra] = {"hbm_read_bytes": int(fe * 1024 * 2), "hbm_write_bytes": int(we * 1024)}
+            fk += fe; wk += we
+        parts["k_bwd_segments"] = {"hbm_read_bytes": int(pick(fetch, k) * 1024 * 2), "hbm_write_bytes": int(pick(write, k) * 1024)}
     rd, wr = int(fk * 1024 * 2), int(wk * 1024)
     tj[k] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "total": rd + wr, "algorithmic": alg[k],
              "fetch_size_kib_reported": round(fk), "write_size_kib_reported": round(wk)}
+    if parts:
+        tj[k]["kernels"] = parts
 json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(tj, indent=1))
