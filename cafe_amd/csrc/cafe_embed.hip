@@ -993,9 +993,12 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
 }
 
 // Between the two halves of the split update: the non-empty entries, gathered into a list (one counter update per
-// 1024 entries).  list[i] = {row key, a lookup of the row, 1 plain / 2 atomic, entry index = where the row's sum is}.
+// 1024 entries).  list[i] = {address of the table row (two words), 1 plain / 2 atomic, entry index = where the row's sum
+// is}: the address is worked out here, beside the insert, so the update kernel behind the migration starts with it.
 __global__ void __launch_bounds__(256) k_bwd_compact(int total, const uint4 *__restrict__ entries, uint32_t *__restrict__ ecount,
-                                                     uint4 *__restrict__ list) {
+                                                     uint4 *__restrict__ list, const int32_t *__restrict__ fields,
+                                                     float *__restrict__ w_hot, float *const *__restrict__ w_cold,
+                                                     const int64_t *__restrict__ cold_base, int hotn, int batch, int dim) {
     __shared__ uint32_t wcnt[4], s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e0 = (blockIdx.x * 256 + tid) * 4;
@@ -1021,7 +1024,10 @@ __global__ void __launch_bounds__(256) k_bwd_compact(int total, const uint4 *__r
     uint32_t at = s_base + before + inc - mine;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (en[k].z != 0u) { en[k].w = (uint32_t)(e0 + k); list[at++] = en[k]; }
+        if (en[k].z != 0u) {
+            const unsigned long long a = (unsigned long long)row_ptr(en[k].x, en[k].y, fields, w_hot, w_cold, cold_base, hotn, batch, dim);
+            list[at++] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), en[k].z, (uint32_t)(e0 + k));
+        }
 }
 
 // Second half of the split update: list entry = one table row, W[row] -= lr * sums[entry] (plain read-modify-write;
@@ -1041,7 +1047,7 @@ __global__ void __launch_bounds__(256) k_bwd_apply(const uint32_t *__restrict__ 
     const uint32_t n = *ecount;
     for (uint32_t i = blockIdx.x * G + grp; i < n; i += gridDim.x * G) {
         const uint4 en = list[i];
-        float *row = row_ptr(en.x, en.y, fields, w_hot, w_cold, cold_base, hotn, batch, dim);
+        float *row = reinterpret_cast<float *>(((unsigned long long)en.y << 32) | en.x);
         float4 sm[VPL], w[VPL];
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
@@ -1146,7 +1152,8 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         if (pst != st) CAFE_HIP_CHECK(hipStreamWaitEvent(st, t->ev_plan, 0));
         if (t->timing) (void)hipEventRecord(t->ev_t[1][0], st);
         CAFE_SEG_ALL(true)
-        hipLaunchKernelGGL(k_bwd_compact, dim3((total + 1023) / 1024), dim3(256), 0, st, total, entries, ecount, elist);
+        hipLaunchKernelGGL(k_bwd_compact, dim3((total + 1023) / 1024), dim3(256), 0, st, total, entries, ecount, elist, d_fields, t->d_w_hot,
+                           t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim);
         if (t->timing) (void)hipEventRecord(t->ev_t[1][1], st);
         if (!t->ev_sums) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_sums, kDeviceEvent));
         CAFE_HIP_CHECK(hipEventRecord(t->ev_sums, st));

@@ -92,10 +92,13 @@ int cafe_sketch_rebuild_free_list(cafe_sketch_t *s, cafe_stream_t stream);
 
 /* Options (tuning and test aids; results never depend on them): "serial_insert" (1 = always use the one-lane in-order
  * kernel), "max_rounds" (rounds the fix-point kernel of the parallel insert may take before the batch counts as not
- * settled; default 6), "target_items" (ids per bucket-owner workgroup, default 320), "hot_bypass" (0 = ids that are
+ * settled; default 6), "target_items" (ids per bucket-owner workgroup, default 448), "hot_bypass" (0 = ids that are
  * already hot go through the owner rounds too), "hot_table" (1 = sort-free hot owner with a per-wave LDS slot table),
- * "owner_cap" (1024 / 2048 / 8192 = fixed owner capacity; 0 = chosen from the last batch's largest partition),
- * "plan_ahead" (0 = cafe_forward_dev does not plan the insert that follows), "overlap" (bit 0: the plan of an insert,
+ * "owner_cap" (1536 / 2048 / 8192 = fixed owner capacity; 0 = chosen from the largest partitions of the last batches),
+ * "plan_ahead" (0 = cafe_forward_dev does not plan the insert that follows), "ids_ready" (1 = the id batches handed to
+ * cafe_forward_dev are complete in memory before the call is made, so the plan may start before the gather),
+ * "split_update" (0 / 1 / 2 = cafe_backward_update_dev updates the tables with one kernel / with two by the library's
+ * rule / always with two: segment sums on a third stream beside the sketch insert, row updates behind the migration), "overlap" (bit 0: the plan of an insert,
  * bit 1: the update's partition passes run on the handle's second stream; 0 = one stream), "fuse_fields" (0 =
  * cafe_backward_update_dev with per_field always issues field by field), "verify", "move_cap" (moves one main
  * partition accepts per round, at most 512: a test aid), "exact_reset" (accepted and ignored: the reset decision is
