@@ -793,8 +793,7 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                                                       float *__restrict__ w_hot, float *const *__restrict__ w_cold,
                                                       const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr,
                                                       const int32_t *__restrict__ skip_if_2, int gstride,
-                                                      uint32_t *__restrict__ ecount, uint4 *__restrict__ entries,
-                                                      float4 *__restrict__ sums) {
+                                                      uint4 *__restrict__ entries, float4 *__restrict__ sums) {
     CAFE_KWIN(6);
     __shared__ __attribute__((aligned(16))) unsigned long long key[kBwdCap];
     __shared__ float4 bpart[2][VPL][256];      // border partial sums: [0] head of a group's range, [1] tail
@@ -1035,9 +1034,7 @@ __global__ void __launch_bounds__(256) k_bwd_compact(int total, const uint4 *__r
 // per row, grid-stride over the *ecount rows of the list.
 template <int LPG, int VPL>
 __global__ void __launch_bounds__(256) k_bwd_apply(const uint32_t *__restrict__ ecount, const uint4 *__restrict__ list,
-                                                   const float4 *__restrict__ sums, const int32_t *__restrict__ fields,
-                                                   float *__restrict__ w_hot, float *const *__restrict__ w_cold,
-                                                   const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr,
+                                                   const float4 *__restrict__ sums, int dim, float lr,
                                                    const int32_t *__restrict__ skip_if_2) {
     CAFE_KWIN(7);
     if (skip_if_2 && *skip_if_2 == 2) return;            // see k_bwd_segments
@@ -1125,7 +1122,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     static const int emit_grid = getenv("CAFE_EMIT_GRID") ? atoi(getenv("CAFE_EMIT_GRID")) : 1536;
 #define CAFE_SEG(L, V, E)                                                                                                \
     hipLaunchKernelGGL((k_bwd_segments<L, V, E>), dim3(E ? std::min(grid, emit_grid) : grid), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
-                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_if_2, gs, ecount, entries, sums)
+                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_if_2, gs, entries, sums)
 #define CAFE_SEG_ALL(E)                                                                                                  \
     if (vpl == 1) {                                                                                                      \
         switch (lpg) {                                                                                                   \
@@ -1169,8 +1166,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         const int agrid = std::max(1, std::min((total + G - 1) / G, 4096));
         if (t->timing) (void)hipEventRecord(t->ev_t[4][0], st);
 #define CAFE_APPLY(L, V)                                                                                                 \
-    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, d_fields, t->d_w_hot, t->d_w_cold, \
-                       t->d_cold_base, t->hotn, batch, t->dim, lr, skip_if_2)
+    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, t->dim, lr, skip_if_2)
         if (vpl == 1) {
             switch (lpg) {
                 case 1: CAFE_APPLY(1, 1); break;
@@ -1313,9 +1309,10 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             s->ev_chain[0] = s->ev_chain[1] = nullptr;
             if (rc) return 1;
             if (side != st && !plan_done) {
-                // the partition passes of the update (they read the routing only) beside the insert.  (The update itself
-                // stays behind the migration: run beside the insert it slowed the insert's latency-bound kernels by
-                // more than it saved, and hot rows are not disjoint from migration targets after a reset.)
+                // the partition passes of the update (they read the routing only) beside the insert.  (The row updates
+                // stay behind the migration: a migrated row is copied before it is updated, and hot rows are not disjoint
+                // from migration targets after a reset.  Run beside the insert as a whole, the update slowed the insert's
+                // latency-bound kernels by more than it saved; its gradient pass alone -- the split form -- pays.)
                 if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, split ? 17 : 1)) return 1;
                 plan_done = true;
                 if (split) {
@@ -1337,21 +1334,25 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             s->host_us[1] += t_wait - t_begin; s->host_us[2] += now_us() - t_wait; s->host_us[3] += 1;
             if (!rejected) {
                 s->force_cap_once = 0;
-                if (getenv("CAFE_DEBUG_SYNC")) {
+                if (const char *report = getenv("CAFE_STUCK_REPORT")) {
+                    // diagnostic: wait here for everything the step queued (10 s at most); a step that does not finish
+                    // is reported to the named file with the state of every stream and event it uses, and the call fails
                     const double t_dbg = now_us();
                     for (;;) {
                         const hipError_t a = hipStreamQuery(st), b = s->low_stream ? hipStreamQuery(s->low_stream) : hipSuccess;
                         if (a == hipSuccess && b == hipSuccess) break;
                         if (now_us() - t_dbg > 10e6) {
                             auto name = [](hipError_t e) { return e == hipSuccess ? "done" : e == hipErrorNotReady ? "busy" : "error"; };
-                            FILE *dbg = fopen("gpurun_out/cafe_stuck.txt", "w");
-                            if (!dbg) dbg = stderr;
-                            fprintf(dbg, "[cafe] step %u stuck: st %s low %s side %s | ev_gn %s ev_fwd %s t.ev_plan %s t.ev_sums %s | split %d sums_done %d plan_done %d\n",
-                                    s->call_seq, name(a), name(b), name(hipStreamQuery(s->side_stream)), name(hipEventQuery(s->ev_gn)),
-                                    name(hipEventQuery(s->ev_fwd)), t->ev_plan ? name(hipEventQuery(t->ev_plan)) : "-",
-                                    t->ev_sums ? name(hipEventQuery(t->ev_sums)) : "-", (int)split, (int)sums_done, (int)plan_done);
-                            fflush(dbg);
-                            abort();
+                            if (FILE *dbg = fopen(report, "w")) {
+                                fprintf(dbg, "step %u does not finish: caller's stream %s, second stream %s, third stream %s | events: norms %s, "
+                                        "gather %s, partition passes %s, segment sums %s | split %d sums queued %d partition passes queued %d\n",
+                                        s->call_seq, name(a), name(hipStreamQuery(s->side_stream)), name(b), name(hipEventQuery(s->ev_gn)),
+                                        name(hipEventQuery(s->ev_fwd)), t->ev_plan ? name(hipEventQuery(t->ev_plan)) : "-",
+                                        t->ev_sums ? name(hipEventQuery(t->ev_sums)) : "-", (int)split, (int)sums_done, (int)plan_done);
+                                fclose(dbg);
+                            }
+                            set_error("cafe_backward_update_dev: step %u does not finish (report in %s)", s->call_seq, report);
+                            return 1;
                         }
                     }
                 }
