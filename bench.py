@@ -253,7 +253,7 @@ def main():
     dt = windows[len(windows) // 2] if reps % 2 else 0.5 * (windows[reps // 2 - 1] + windows[reps // 2])
 
     # roofline: the library records HIP events around its kernels on the stream they are launched on (timing mode);
-    # measured in a few extra steps behind the timed region.  [0] k_forward, [1] k_bwd_segments (+ k_bwd_compact), [2] the
+    # measured in a few extra steps behind the timed region.  [0] k_forward, [1] k_bwd_segments, [2] the
     # insert chain (k_round1 .. k_commit), [3] k_grad_norm, [4] k_bwd_apply (the second kernel of the update when a step
     # runs it in two: the segment sums on the library's third stream beside the insert, the row updates behind the
     # migration; [1] + [4] is then the update's launch time)

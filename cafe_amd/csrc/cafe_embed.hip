@@ -1149,9 +1149,9 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         if (pst != st) CAFE_HIP_CHECK(hipStreamWaitEvent(st, t->ev_plan, 0));
         if (t->timing) (void)hipEventRecord(t->ev_t[1][0], st);
         CAFE_SEG_ALL(true)
+        if (t->timing) (void)hipEventRecord(t->ev_t[1][1], st);          // the gradient pass alone (as a profiler reports it)
         hipLaunchKernelGGL(k_bwd_compact, dim3((total + 1023) / 1024), dim3(256), 0, st, total, entries, ecount, elist, d_fields, t->d_w_hot,
                            t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim);
-        if (t->timing) (void)hipEventRecord(t->ev_t[1][1], st);
         if (!t->ev_sums) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_sums, kDeviceEvent));
         CAFE_HIP_CHECK(hipEventRecord(t->ev_sums, st));
         if (!t->h_rows) { CAFE_HIP_CHECK(hipHostMalloc((void **)&t->h_rows, 64, hipHostMallocDefault)); t->h_rows[0] = 0; }
