@@ -70,3 +70,48 @@ def test_cfg3_full_size_steps(oracle_mod):
     _close(coll.weight_high.cpu().numpy(), cpu.w_hot, "hot table")
     for f in range(F):
         _close(coll.weight_hash[f].cpu().numpy(), cpu.w_cold[f], f"cold table {f}")
+
+
+def test_cfg3_split_update_equals_one_kernel_update():
+    """Size-independent property at the full cfg3 size, too long a run for the oracle: the update in two kernels (segment
+    sums on the third stream beside the insert, row updates behind the migration) and the update as one kernel are the
+    same arithmetic in the same order -- 120 steps from the same seed leave the same sketch (every slot, bit for bit),
+    the same ins[], scores and routing in every step, and the same tables: rows of partitions that fit one tile are
+    bit-identical (more than 90 % of the hot rows), the rows of a partition that holds a heavy row (float atomics, any
+    order, in both forms, 120 steps of them) within 1e-5 relative, the path's tolerance."""
+    from cafe_amd.collection import CafeEmbeddingCollection
+    from cafe_amd.config import workload
+    from oracle import cafe_oracle
+    wl = workload("cfg3")
+    F, B, D, thr, lr = wl.num_fields, wl.batch, wl.dim, 20, 0.05
+    colls = []
+    for mode in (0, 2):
+        c = CafeEmbeddingCollection(wl.counts, D, wl.hotn, wl.hash_sizes, wl.offsets, threshold=thr, alpha=wl.alpha, seed=4)
+        c.sketch.set_option("split_update", mode)
+        colls.append(c)
+    steps = 120
+    ids_all = wl.make_ids(78, steps=16)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    for step in range(steps):
+        d_ids = torch.from_numpy(ids_all[step % 16]).cuda()
+        grad = torch.randn(F, B, D, device="cuda", generator=gen)
+        res = []
+        for c in colls:
+            out = c.forward(d_ids)
+            scores, ins = c.backward_update(grad, lr, per_field_calls=True)
+            res.append((c._buf["que"].clone(), ins.clone(), scores.clone(), out))
+        assert torch.equal(res[0][0], res[1][0]), f"step {step}: routing"
+        assert torch.equal(res[0][1], res[1][1]), f"step {step}: ins"
+        assert torch.equal(res[0][2], res[1][2]), f"step {step}: scores"
+    bad = cafe_oracle.states_equal(colls[0].sketch.state(), colls[1].sketch.state())
+    assert not bad, bad[:3]
+    a, b = colls[0].weight_high, colls[1].weight_high
+    same = (a == b).all(dim=1)
+    assert same.float().mean().item() > 0.9, same.float().mean().item()
+    err = ((a - b).abs().max() / b.abs().max()).item()
+    assert err <= RTOL, err
+    for f in range(F):
+        a, b = colls[0].weight_hash[f], colls[1].weight_hash[f]
+        err = ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+        assert err <= RTOL, (f, err)
+    assert colls[0].sketch.counters()["cadence_miss"] == 0 and colls[1].sketch.counters()["inorder_calls"] == 0
