@@ -1700,16 +1700,18 @@ __global__ void __launch_bounds__(kScanBlock) k_finish(
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = blockIdx.x * kScanBlock + tid;
     CAFE_STAMP(1, 0);
-    if (scores_out) {
-        // the scores as every owner formed them, for the caller (sk_embedding_bag.py:189)
+    // the scores as every owner formed them, for the caller (sk_embedding_bag.py:189): written whatever the verdict, but
+    // AFTER this workgroup has published its totals -- the workgroups behind it wait for those, not for the scores
+    auto write_scores = [&]() {
+        if (!scores_out) return;
         field_sums(g, sc, fsum);
         __syncthreads();
         const ScoreSrc ss = score_src(g, sc, fsum);
         if (i < g.n) scores_out[i] = ss.at((uint32_t)i);
-    }
+    };
     CAFE_STAMP(1, 1);
     const bool live = !ctl->overflow && ctl->final_round != 0;
-    if (!live) return;             // uniform; k_commit decides what happens to the batch
+    if (!live) { write_scores(); return; }             // uniform; k_commit decides what happens to the batch
     if (tid == 0) s_cross = 0;
     uint32_t pop = 0, push = 0, clk = 0, cross = 0;
     if (i < g.n) {
@@ -1751,6 +1753,7 @@ __global__ void __launch_bounds__(kScanBlock) k_finish(
         __hip_atomic_store(&agg[2 * blockIdx.x + 1], (1ull << 63) | ((unsigned long long)s_cross << 24) | t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_base[0] = s_base[1] = s_base[2] = s_base[3] = 0;
     }
+    write_scores();
     __syncthreads();
     {
         unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
