@@ -1837,8 +1837,22 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
     DevState *st = A.st;
     const Ctl *ctl = A.ctl;
     CAFE_STAMP(2, 0);
-    // every workgroup takes the same decision from the same words (none of them changes before the last one is done);
-    // all of them are requested before the first is looked at
+    // what the copy loop below needs first -- the scalars of the sketch and this workgroup's partition -- is requested
+    // together with the words of the decision, not behind it (none of them changes before the last workgroup is done)
+    const uint32_t head = st->fifo_head, len0 = st->fifo_len;
+    const int32_t clk0 = st->clk;
+    const uint32_t gflip = (uint32_t)st->flip;
+    const int part_mine = blockIdx.x;
+    int tot_mine = 0;
+    uint32_t offa_mine = 0, offb_mine = 0;
+    if (part_mine < g.P1 + g.P2) {
+        tot_mine = (int)A.stage_tot[part_mine];
+        if (part_mine < g.P1) { offa_mine = A.off[2 * part_mine]; offb_mine = A.off[2 * part_mine + 2]; }
+        else { offa_mine = A.off[off_lru0(g) + (part_mine - g.P1)]; offb_mine = A.off[off_lru0(g) + (part_mine - g.P1) + 1]; }
+    } else if (g.hot && part_mine < g.P1 + g.P2 + g.PH) {
+        offa_mine = A.off[off_hot0(g) + (part_mine - g.P1 - g.P2)]; offb_mine = A.off[off_hot0(g) + (part_mine - g.P1 - g.P2) + 1];
+    }
+    // every workgroup takes the same decision from the same words; all of them are requested before the first is looked at
     if (tid < 64) {
         const uint32_t len0 = st->fifo_len, w_over = ctl->overflow, w_final = ctl->final_round, w_pop = ctl->totals[0],
                        w_push = ctl->totals[1];
@@ -1861,17 +1875,15 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
     __syncthreads();
     const int verdict = s_verdict;
     CAFE_STAMP(2, 1);
-    const uint32_t head = st->fifo_head, len0 = st->fifo_len;
-    const int32_t clk0 = st->clk;
     if (verdict == 0) {
         const int nparts = g.P1 + g.P2 + (g.hot ? g.PH : 0);
-        const uint32_t gflip = (uint32_t)st->flip;
         for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
+            const bool mine = part == part_mine;
             if (part >= g.P1 + g.P2) {
                 // final scores of the bypassed hot slots of one hot partition
                 const int ph = part - g.P1 - g.P2;
-                const uint32_t oh0 = A.off[off_hot0(g) + ph];
-                const int nh = (int)(A.off[off_hot0(g) + ph + 1] - oh0);
+                const uint32_t oh0 = mine ? offa_mine : A.off[off_hot0(g) + ph];
+                const int nh = (int)((mine ? offb_mine : A.off[off_hot0(g) + ph + 1]) - oh0);
                 for (int s = tid; s < nh; s += blockDim.x) {
                     const int2 f = A.hfin[oh0 + s];
                     if (f.x >= 0 && (f.x >> 2) >= g.n1) { atomicAdd(&st->bad_commit, 1); continue; }
@@ -1879,14 +1891,15 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
                 }
                 continue;
             }
-            int tot = (int)A.stage_tot[part];
+            int tot = mine ? tot_mine : (int)A.stage_tot[part];
             // Everything below indexes the tables with numbers read from the staging buffers.  They are written by the
             // owners of this very call; the range checks turn a broken invariant into a counted refusal, not a wild store.
-            const int room = part < g.P1 ? (int)(A.off[2 * part + 2] - A.off[2 * part]) + g.evs
-                                         : (int)(A.off[off_lru0(g) + (part - g.P1) + 1] - A.off[off_lru0(g) + (part - g.P1)]);
+            const uint32_t offa = mine ? offa_mine : part < g.P1 ? A.off[2 * part] : A.off[off_lru0(g) + (part - g.P1)];
+            const uint32_t offb = mine ? offb_mine : part < g.P1 ? A.off[2 * part + 2] : A.off[off_lru0(g) + (part - g.P1) + 1];
+            const int room = (int)(offb - offa) + (part < g.P1 ? g.evs : 0);
             if (tot < 0 || tot > room) { if (tid == 0) atomicAdd(&st->bad_commit, 1); tot = 0; }
             if (part < g.P1) {
-                const MainBucket *stage = A.stage_m + A.off[2 * part] + (size_t)part * g.evs;
+                const MainBucket *stage = A.stage_m + offa + (size_t)part * g.evs;
                 for (int s = tid; s < tot; s += blockDim.x) {
                     const int4 *p = reinterpret_cast<const int4 *>(&stage[s]);
                     const int4 m = p[3];
@@ -1917,7 +1930,7 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
                     A.mt[m.y].flip = (uint32_t)m.x;
                 }
             } else {
-                const LruBucket *stage = A.stage_l + A.off[off_lru0(g) + (part - g.P1)];
+                const LruBucket *stage = A.stage_l + offa;
                 for (int s = tid; s < tot; s += blockDim.x) {
                     const int4 *p = reinterpret_cast<const int4 *>(&stage[s]);
                     const int4 m = p[4];
