@@ -63,6 +63,8 @@ SYMBOLS = {
     "cafe_tables_destroy": (ctypes.c_int, [_vp]),
     "cafe_tables_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
     "cafe_tables_kernel_ms": (ctypes.c_int, [_vp, ctypes.c_int, _f32p]),
+    "cafe_gather_que_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "cafe_migrate_que_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "cafe_forward_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "cafe_forward_ml_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cafe_scores_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),

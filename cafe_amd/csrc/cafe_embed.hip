@@ -588,6 +588,78 @@ extern "C" int cafe_migrate_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const in
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same two steps for a routing that another sketch generation produced (the artifact's earlier HotSketch,
+// cafe_ae.hip: ArtifactEvaluation/embeddings/sk_embedding_bag.py:96-118 gathers from `dic`, :178-182 migrates from the
+// re-query): rows chosen by que[] alone.
+// ------------------------------------------------------------------------------------------------
+template <int LPG>
+__global__ void __launch_bounds__(256) k_gather_que(const float *__restrict__ w_hot, float *const *__restrict__ w_cold,
+                                                    const int32_t *__restrict__ hash_size, const int32_t *__restrict__ que,
+                                                    const int32_t *__restrict__ fields, int batch, int total, int dim, int hotn,
+                                                    float *__restrict__ out) {
+    // a lane group per lookup: hot W_h[|q| % hotn], cold W_hash[f][|q| % hash_size[f]]
+    const int groups = (gridDim.x * blockDim.x) / LPG, gi = (blockIdx.x * blockDim.x + threadIdx.x) / LPG, lig = threadIdx.x % LPG;
+    const int dim4 = dim >> 2;
+    for (int i = gi; i < total; i += groups) {
+        const int32_t q = que[i];
+        const int f = fields ? fields[i] : i / batch;
+        const float *row = q < 0 ? w_hot + (size_t)hot_row(q, hotn) * dim
+                                 : w_cold[f] + (size_t)((uint32_t)q % (uint32_t)hash_size[f]) * dim;
+        for (int c = lig; c < dim4; c += LPG)
+            reinterpret_cast<float4 *>(out + (size_t)i * dim)[c] = reinterpret_cast<const float4 *>(row)[c];
+    }
+}
+
+extern "C" int cafe_gather_que_dev(cafe_tables_t *t, const int32_t *d_que, const int32_t *d_fields, int batch, int n,
+                                   float *d_out, cafe_stream_t stream) {
+    if (n <= 0) return 0;
+    if (batch <= 0) { set_error("cafe_gather_que_dev: bad batch %d", batch); return 1; }
+    if (!d_fields && n > t->num_fields * batch) { set_error("cafe_gather_que_dev: %d lookups for %d fields of %d", n, t->num_fields, batch); return 1; }
+    const int lpg = lanes_per_row(t->dim);
+    const int blocks = std::min((n + 256 / lpg - 1) / (256 / lpg), 256 * 32);
+#define CAFE_GQ(L) hipLaunchKernelGGL(k_gather_que<L>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float *)t->d_w_hot, \
+                                      (float *const *)t->d_w_cold, (const int32_t *)t->d_hash_size, d_que, d_fields, batch, n, t->dim, t->hotn, d_out)
+    switch (lpg) {
+        case 1: CAFE_GQ(1); break;
+        case 2: CAFE_GQ(2); break;
+        case 4: CAFE_GQ(4); break;
+        case 8: CAFE_GQ(8); break;
+        case 16: CAFE_GQ(16); break;
+        case 32: CAFE_GQ(32); break;
+        default: CAFE_GQ(64); break;
+    }
+#undef CAFE_GQ
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// W_h[|que[i]|] = W_hash[f][local_id[i] % hash_size[f]] for the lookups with ins[i] != 0 whose re-query says hot
+__global__ void k_migrate_que(float *__restrict__ w_hot, float *const *__restrict__ w_cold, const int32_t *__restrict__ hash_size,
+                              const int64_t *__restrict__ local_ids, const int32_t *__restrict__ que,
+                              const int32_t *__restrict__ fields, const int32_t *__restrict__ ins, int batch, int total, int dim,
+                              int hotn) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total || !ins[i]) return;
+    const int32_t q = que[i];
+    if (q >= 0) return;                                     // SURVEY Q3 fence, as in k_migrate
+    const int f = fields ? fields[i] : i / batch;
+    const int64_t src_row = local_ids[i] % (int64_t)hash_size[f];
+    const float4 *src = reinterpret_cast<const float4 *>(w_cold[f] + (size_t)src_row * dim);
+    float4 *dst = reinterpret_cast<float4 *>(w_hot + (size_t)hot_row(q, hotn) * dim);
+    for (int c = 0; c < (dim >> 2); ++c) dst[c] = src[c];
+}
+
+extern "C" int cafe_migrate_que_dev(cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_que, const int32_t *d_fields,
+                                    const int32_t *d_ins, int batch, int n, cafe_stream_t stream) {
+    if (n <= 0) return 0;
+    if (batch <= 0 || (!d_fields && n > t->num_fields * batch)) { set_error("cafe_migrate_que_dev: bad sizes (batch %d, n %d)", batch, n); return 1; }
+    hipLaunchKernelGGL(k_migrate_que, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->d_w_hot, t->d_w_cold, t->d_hash_size,
+                       d_local_ids, d_que, d_fields, d_ins, batch, n, t->dim, t->hotn);
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // The same for the lookups the parallel insert listed as newly hot (cafe_insert_par.hip: got list), LPG lanes per row.
 // A count of 0xffffffff means the batch was walked in order (no list): then ins[] is scanned.
 template <int LPG>

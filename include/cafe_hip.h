@@ -232,6 +232,15 @@ int cafe_grad_norm_dev(cafe_tables_t *t, const float *d_grad_out, int batch, flo
  *     the free list in pop order, num, and tot -- the double the reference accumulates item by item).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct cafe_ae_sketch cafe_ae_sketch_t;
+/* The gather and the migration for a routing produced by another sketch generation (section E): rows chosen by que[]
+ * alone.  ArtifactEvaluation/embeddings/sk_embedding_bag.py:96-118 (`dic % hot_nums` / `dic % hash_size` behind
+ * `torch.where(dic_mask, ...)`) and :175-182 (`weight_h[dic[x]] = weight_hash[input[x] % hash_size]` for the lookups the
+ * insert reported, with the hot-only fence of SURVEY Q3).  d_fields == NULL: lookup i belongs to field i / batch. */
+int cafe_gather_que_dev(cafe_tables_t *t, const int32_t *d_que, const int32_t *d_fields, int batch, int n, float *d_out,
+                        cafe_stream_t stream);
+int cafe_migrate_que_dev(cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_que, const int32_t *d_fields,
+                         const int32_t *d_ins, int batch, int n, cafe_stream_t stream);
+
 /* :207-209 init(n, Threshold, dr, idx) -> new SS(Threshold, n, dr) (:26-43). */
 int cafe_ae_create(cafe_ae_sketch_t **out, int n, int threshold, double decay_rate);
 int cafe_ae_destroy(cafe_ae_sketch_t *s);

@@ -14,7 +14,7 @@ def pytest_configure(config):
 
 def golden_names():
     g = os.path.join(ROOT, "tests", "golden")
-    other = ("module_", "ae_", "loader_", "pinsage_")       # fixtures of other tests (module steps, AE generation, loader, state file)
+    other = ("module_", "ae_", "aemod_", "loader_", "pinsage_")       # fixtures of other tests (module steps, AE generation, loader, state file)
     return sorted(f[:-4] for f in os.listdir(g) if f.endswith(".npz") and not f.startswith(other))
 
 
