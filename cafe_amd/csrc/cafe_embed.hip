@@ -772,7 +772,7 @@ __global__ void __launch_bounds__(1024) k_bwd_offsets(int Ph, int P, const uint3
                                                       uint32_t *__restrict__ tiles /* [0] = hot tiles, [1] = all tiles, then (p << 8 | t)... */,
                                                       uint32_t *__restrict__ ecount) {
     CAFE_KWIN(4);
-    if (threadIdx.x == 0 && ecount) *ecount = 0;        // entries of the split update (k_bwd_segments<.., true>)
+    if (threadIdx.x == 0 && ecount) *ecount = 0;        // rows of the split update (counted by k_bwd_compact)
     __shared__ uint32_t sh[1024], sh2[1024];
     __shared__ uint32_t carry, carry2;
     if (threadIdx.x == 0) { carry = 0; carry2 = 0; }
