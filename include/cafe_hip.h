@@ -200,7 +200,12 @@ int cafe_backward_sgd_dev(cafe_tables_t *t, const int32_t *d_gids, const int32_t
  *   returns, the remaining kernels are enqueued on `stream` as usual.
  * per_field == 0: ONE batch_insert_val over all fields' ids in field-major order.
  * cafe_forward_dev starts the plan of this insert beside its gather kernel when it is called with d_local_ids; the
- * plan is used if this call follows with the same d_local_ids and no sketch call in between. */
+ * plan is used if this call follows with the same d_local_ids and no sketch call in between.
+ * Streams: a large step (>= 32768 lookups) also uses the handle's own streams -- the plan and the update's partition
+ *   passes on a second one, and, by the library's rule (option "split_update"), the update's pass over the gradient on
+ *   a third one beside the insert, with the row updates behind the migration on `stream`.  All of it is ordered before
+ *   the call's last kernel on `stream`: d_grad_out, d_que and the id arrays must stay unchanged until the work queued on
+ *   `stream` by this call is complete, nothing else. */
 int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
                              const int32_t *d_que, const float *d_grad_out, int batch, float lr, float *d_scores,
                              int32_t *d_ins, int per_field, cafe_stream_t stream);
