@@ -51,11 +51,13 @@ write_summary(write, "WRITE_SIZE", os.path.join(out, f"{tag}_pmc_write_size_summ
 
 
 def pick(res, prefix):
+    """mean per launch of the kernel whose name starts with `prefix`; of several instantiations, the one launched most"""
+    best = None
     for k, v in res.items():
         name = k.replace("void ", "").replace("cafe::", "")
-        if name.startswith(prefix):
-            return v[0]
-    return None
+        if name.startswith(prefix) and (best is None or v[1] > best[1]):
+            best = v
+    return None if best is None else best[0]
 
 
 F, B, D = 26, 8192, 128

@@ -7,6 +7,9 @@ tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_fetch gpurun_out/${tag}_write
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -o ${tag} -- python3 bench.py --steps 100 --warmup 5 --repetitions 3 --no-cpu-baseline > gpurun_out/${tag}_stats.log 2>&1 || exit 1
+# (the short counter runs start from a cold sketch, whose churn keeps the library's rule from splitting the update: forced here,
+# so that the counters see the kernels of the steady state)
+export CAFE_SPLIT_UPDATE=2
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -o ${tag} -- python3 bench.py --steps 6 --warmup 2 --preheat 30 --repetitions 1 --no-cpu-baseline > gpurun_out/${tag}_fetch.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -o ${tag} -- python3 bench.py --steps 6 --warmup 2 --preheat 30 --repetitions 1 --no-cpu-baseline > gpurun_out/${tag}_write.log 2>&1 || exit 1
 find gpurun_out/${tag}_stats gpurun_out/${tag}_fetch gpurun_out/${tag}_write -type f | head -20
