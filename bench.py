@@ -54,6 +54,9 @@ def parse():
                     help="do NOT tell the library that a batch's ids are resident before forward is called (they are: the bench "
                          "holds every id batch in HBM before the timed region); the plan of the insert then waits for everything "
                          "queued on the stream instead of starting at once")
+    ap.add_argument("--no-hint", action="store_true",
+                    help="do NOT name the next step's id batch before the update (cafe_forward_hint_dev): the next gather is "
+                         "then queued only after the host has seen the insert's verdict and returned")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -210,6 +213,7 @@ def main():
     out = torch.empty(F, B, D, device="cuda")
 
     counts_dev = torch.tensor(wl.counts, device="cuda", dtype=torch.int64)[:, None]
+    use_hint = world == 1 and not args.no_hint
 
     def step(i, timed_idx=None):
         if args.drift and i and i % nb == 0:
@@ -217,6 +221,8 @@ def main():
                 t.add_(args.drift).remainder_(counts_dev)
                 t[0].clamp_(min=1)
         eng.forward(ids_dev[i % nb], out=out)
+        if use_hint and not (args.drift and (i + 1) % nb == 0):
+            eng.hint_next(ids_dev[(i + 1) % nb], out)      # a data loader knows its next batch: name it before the update
         eng.backward_update(grad, args.lr, per_field_calls=cadence)
         if world > 1 and not (args.drift and (i + 1) % nb == 0):
             eng.prefetch(ids_dev[(i + 1) % nb])       # the next batch's ids are known: route them one step ahead
@@ -357,7 +363,10 @@ def main():
                                         {True: "one per field (reference cadence), run as one insert per step",
                                          "loop": "one per field, issued one by one", False: "one per step"}[cadence]),
                        "parallelism": "single GPU" if world == 1 else f"id-hash sharded x{world}, RCCL all-to-all",
-                       "host_syncs_in_step": getattr(eng, "host_syncs_in_step", 0),
+                       # N = 1: every step waits once on the host for the device's verdict on the insert (polling a pinned
+                       # snapshot); with next_ids_hint the next gather is queued before that wait
+                       "host_syncs_in_step": 1 if world == 1 else getattr(eng, "host_syncs_in_step", 0),
+                       "next_ids_hint": int(use_hint),
                        "ids_ready": int(world == 1 and not args.ids_on_stream),
                        "preheat_steps": args.preheat, "id_batches": nb, "drift": args.drift, "repetitions": reps,
                        "cadence_miss": (eng.sketch.counters()["cadence_miss"] if getattr(eng, "sketch", None) else None)},

@@ -66,6 +66,8 @@ SYMBOLS = {
     "cafe_gather_que_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
     "cafe_migrate_que_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "cafe_forward_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "cafe_forward_hint_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "cafe_forward_hint_stats": (ctypes.c_int, [_vp, _vp]),
     "cafe_forward_ml_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cafe_scores_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "cafe_scores_noalloc_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),

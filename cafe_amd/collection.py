@@ -90,14 +90,44 @@ class CafeEmbeddingCollection:
         return t
 
     # ---------------------------------------------------------------------------------------------
+    def _route_bufs(self, n, which):
+        """Two sets of (global ids, routing) arrays, used by alternate steps: the forward named by hint_next() is queued
+        while the update of the current step still reads its own set."""
+        return (self._get(f"gids{which}", (n,), torch.int32), self._get(f"que{which}", (n,), torch.int32))
+
+    def hint_next(self, local_ids, out):
+        """Names the next forward(local_ids, out=out) call (include/cafe_hip.h, cafe_forward_hint_dev): the
+        backward_update() of the current step queues it before waiting for the device's verdict.  `local_ids` (a data
+        loader's next batch) must be complete in memory; `out` is required, it is the array the queued gather writes."""
+        assert local_ids.dtype == torch.int64 and local_ids.is_cuda and local_ids.shape[0] == self.F and local_ids.is_contiguous()
+        assert out is not None and out.is_contiguous()
+        B = local_ids.shape[1]
+        which = 1 - getattr(self, "_which", 0)
+        gids, que = self._route_bufs(self.F * B, which)
+        self._hint = (local_ids.data_ptr(), out.data_ptr(), B, which, local_ids)
+        _lib.check(self.L.cafe_forward_hint_dev(self.sketch.h, self.tables, _ptr(local_ids), B, _ptr(gids), _ptr(que),
+                                                _ptr(out), _stream()), "cafe_forward_hint_dev")
+
+    def hint_stats(self):
+        """(announced forwards found queued, queued forwards dropped because their step was rejected)"""
+        o = (ctypes.c_int64 * 2)()
+        _lib.check(self.L.cafe_forward_hint_stats(self.sketch.h, o), "cafe_forward_hint_stats")
+        return int(o[0]), int(o[1])
+
     def forward(self, local_ids, out=None):
         """local_ids: [F, B] int64 on the device.  Returns [F, B, D] float32; keeps ids/routing for backward."""
         assert local_ids.dtype == torch.int64 and local_ids.is_cuda and local_ids.shape[0] == self.F
         local_ids = local_ids.contiguous()
         B = local_ids.shape[1]
         n = self.F * B
-        gids = self._get("gids", (n,), torch.int32)
-        que = self._get("que", (n,), torch.int32)
+        hint = getattr(self, "_hint", None)
+        self._hint = None
+        if hint is not None and out is not None and hint[:3] == (local_ids.data_ptr(), out.data_ptr(), B):
+            self._which = hint[3]               # the call that was announced: same arrays, found queued by the library
+        else:
+            self._which = 1 - getattr(self, "_which", 1)
+        gids, que = self._route_bufs(n, self._which)
+        self._buf["gids"], self._buf["que"] = gids, que
         if out is None:
             out = torch.empty(self.F, B, self.dim, device=self.device)
         _lib.check(self.L.cafe_forward_dev(self.sketch.h, self.tables, _ptr(local_ids), B, _ptr(gids), _ptr(que),

@@ -53,6 +53,10 @@ struct DevState {
     int32_t bad_commit;      // cumulative: staged entries the commit kernel refused (index out of range) -- always 0
     int32_t why[3];          // cumulative, batches given to the in-order kernel (or rejected): [0] a workspace limit,
                              // [1] the rounds that were enqueued did not settle it, [2] the free list changed state
+    uint32_t rejected_seq;   // call number of the last insert that was rejected (0: none).  The kernels queued behind an
+                             // insert whose verdict the host has not seen compare it with their own call number; unlike
+                             // `fallback` it is never cleared, so a plan made ahead for the NEXT call cannot hide a rejection
+    uint32_t pad2[3];
 };
 
 // What the kernel that closes an insert leaves in pinned host memory: the host reads it lagging, without a sync.

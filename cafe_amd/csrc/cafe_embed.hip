@@ -242,11 +242,13 @@ static bool want_split_update(const cafe_sketch_t *s, const cafe_tables_t *t, in
 
 static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,
                            int batch, int total, float lr, hipStream_t st, hipStream_t pst, int part = 3,
-                           const int32_t *skip_if_2 = nullptr, int gstride = 0);
+                           const uint32_t *skip_rej = nullptr, uint32_t skip_seq = 0, int gstride = 0);
 
+// spec: queued by cafe_backward_update_dev for the forward the caller has named (cafe_forward_hint_dev), behind the update
+// kernels of a step whose verdict the host has not seen: the plan then waits for that step's commit kernel on the device
 static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_in_gids,
                           const int32_t *d_fields, int batch, long total_l, int32_t *d_gids, int32_t *d_que, float *d_out,
-                          hipStream_t st) {
+                          hipStream_t st, bool spec = false) {
     if (total_l == 0) return 0;
     if (batch <= 0 || total_l < 0 || total_l > 0x7fffffffL / 4) { set_error("cafe forward: bad size %ld", total_l); return 1; }
     if (pair_ok(s, t, "cafe_forward_dev")) return 1;
@@ -263,7 +265,8 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
         s->side_stream != st && total >= 32768 && total <= cafe::kParMaxIds && t->num_fields <= kMaxSeg) {
         if (s->plan_valid) s->unused_plans++;
         s->plan_valid = 0;
-        const bool reset_due = s->adjust && (double)cafe::real_n_bound(s) > s->lim * 1.2;
+        // (queued ahead of the verdict, real_n is only known as a bound: a reset at the next insert marks the plan stale)
+        const bool reset_due = !spec && s->adjust && (double)cafe::real_n_bound(s) > s->lim * 1.2;
         if (s->unused_plans < 2 && !reset_due) {
             if (cafe::par_prepare(s, total)) return 1;
             // What the plan reads must be final: the sketch (the last insert's commit) and the ids.  Normally that means
@@ -272,7 +275,13 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
             // if the host has also seen the last insert's snapshot (cafe_backward_update_dev waits for it), nothing is
             // left to wait for: the plan starts at once, beside the previous step's update kernels instead of beside
             // this gather.
-            if (s->opt_ids_ready && s->call_seq == s->base_seq) {
+            if (spec) {
+                // behind the commit kernel of the insert just queued (its completion signal), beside the migration, the
+                // row updates and this gather
+                CAFE_HIP_CHECK(hipStreamWaitEvent(s->side_stream, s->ev_commit, 0));
+                if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream)) return 1;
+                plan_launched = true;
+            } else if (s->opt_ids_ready && s->call_seq == s->base_seq) {
                 if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream)) return 1;
                 plan_launched = true;
             } else {
@@ -313,7 +322,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
         // behind it on the third stream (in a training step: under the dense model's forward and backward), and the
         // gradient pass of the split update follows them there without a cross-stream hand-over.
         CAFE_HIP_CHECK(hipStreamWaitEvent(s->low_stream, s->ev_fwd, 0));
-        if (backward_common(t, nullptr, d_que, nullptr, batch, total, 0.f, st, s->low_stream, 17, nullptr, 0)) return 1;
+        if (backward_common(t, nullptr, d_que, nullptr, batch, total, 0.f, st, s->low_stream, 17)) return 1;
         t->bwd_plan_que = d_que;
         t->bwd_plan_fwd = s->fwd_count;
     }
@@ -355,8 +364,30 @@ extern "C" int cafe_forward_ml_dev(cafe_sketch_t *s, cafe_tables_t *t, const int
 
 extern "C" int cafe_forward_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, int batch,
                                 int32_t *d_gids, int32_t *d_que, float *d_out, cafe_stream_t stream) {
+    cafe_sketch::Hint &h = s->hint;
+    if (h.valid) {
+        const bool same = h.t == t && h.ids == d_local_ids && h.batch == batch && h.gids == d_gids && h.que == d_que &&
+                          h.out == d_out && h.st == (hipStream_t)stream;
+        const bool queued = same && h.enqueued;
+        h.valid = 0; h.enqueued = 0;
+        if (queued) { s->hint_used++; return 0; }       // cafe_backward_update_dev has queued exactly this call
+    }
     return forward_common(s, t, d_local_ids, nullptr, nullptr, batch, (long)t->num_fields * batch, d_gids, d_que, d_out,
                           (hipStream_t)stream);
+}
+
+extern "C" int cafe_forward_hint_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, int batch,
+                                     int32_t *d_gids, int32_t *d_que, float *d_out, cafe_stream_t stream) {
+    cafe_sketch::Hint &h = s->hint;
+    h.valid = d_local_ids != nullptr && batch > 0;
+    h.enqueued = 0;
+    h.t = t; h.ids = d_local_ids; h.batch = batch; h.gids = d_gids; h.que = d_que; h.out = d_out; h.st = (hipStream_t)stream;
+    return 0;
+}
+
+extern "C" int cafe_forward_hint_stats(cafe_sketch_t *s, int64_t *out2) {
+    out2[0] = s->hint_used; out2[1] = s->hint_cancelled;
+    return 0;
 }
 
 extern "C" int cafe_forward_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_fields,
@@ -864,7 +895,7 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                                                       const int32_t *__restrict__ fields, const float *__restrict__ grad,
                                                       float *__restrict__ w_hot, float *const *__restrict__ w_cold,
                                                       const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr,
-                                                      const int32_t *__restrict__ skip_if_2, int gstride,
+                                                      const uint32_t *__restrict__ skip_rej, uint32_t skip_seq, int gstride,
                                                       uint4 *__restrict__ entries, float4 *__restrict__ sums) {
     CAFE_KWIN(6);
     __shared__ __attribute__((aligned(16))) unsigned long long key[kBwdCap];
@@ -873,9 +904,9 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
     __shared__ uint16_t srank[EMIT ? kBwdCap : 2];     // EMIT: rows that start before sorted position j
     __shared__ uint32_t wrows[4], s_ebase;
     const int tid = threadIdx.x;
-    // queued behind an insert whose verdict the host has not seen yet: if the device rejected it (DevState::fallback
-    // == 2) the host issues the step again, and this update with it
-    if (skip_if_2 && *skip_if_2 == 2) return;
+    // queued behind an insert whose verdict the host has not seen yet: if the device rejected it (DevState::rejected_seq
+    // names that call) the host issues the step again, and this update with it
+    if (skip_rej && *skip_rej == skip_seq) return;
     const uint32_t ntiles = tiles[1];
     for (uint32_t tile_at = blockIdx.x; tile_at < ntiles; tile_at += gridDim.x) {
     // the tile index is kept in 8 bits; a partition with more tiles lets its last workgroup walk the rest
@@ -1107,9 +1138,9 @@ __global__ void __launch_bounds__(256) k_bwd_compact(int total, const uint4 *__r
 template <int LPG, int VPL>
 __global__ void __launch_bounds__(256) k_bwd_apply(const uint32_t *__restrict__ ecount, const uint4 *__restrict__ list,
                                                    const float4 *__restrict__ sums, int dim, float lr,
-                                                   const int32_t *__restrict__ skip_if_2) {
+                                                   const uint32_t *__restrict__ skip_rej, uint32_t skip_seq) {
     CAFE_KWIN(7);
-    if (skip_if_2 && *skip_if_2 == 2) return;            // see k_bwd_segments
+    if (skip_rej && *skip_rej == skip_seq) return;       // see k_bwd_segments
     constexpr int G = 256 / LPG;
     const int lig = threadIdx.x % LPG, grp = threadIdx.x / LPG;
     const int dim4 = dim >> 2;
@@ -1150,7 +1181,7 @@ __global__ void __launch_bounds__(256) k_bwd_apply(const uint32_t *__restrict__ 
 // the offsets pass zeroes the entry counter).
 static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que, const float *d_grad_out,
                            int batch, int total, float lr, hipStream_t st, hipStream_t pst, int part,
-                           const int32_t *skip_if_2, int gstride) {
+                           const uint32_t *skip_rej, uint32_t skip_seq, int gstride) {
     if (total <= 0) return 0;
     const int64_t rows = (int64_t)t->hotn + t->total_cold_rows;
     if (rows >= (int64_t)0xFFFFFFFFLL) { set_error("cafe_backward_sgd_dev: more than 2^32 table rows"); return 1; }
@@ -1194,7 +1225,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     static const int emit_grid = getenv("CAFE_EMIT_GRID") ? atoi(getenv("CAFE_EMIT_GRID")) : 1536;
 #define CAFE_SEG(L, V, E)                                                                                                \
     hipLaunchKernelGGL((k_bwd_segments<L, V, E>), dim3(E ? std::min(grid, emit_grid) : grid), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
-                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_if_2, gs, entries, sums)
+                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_rej, skip_seq, gs, entries, sums)
 #define CAFE_SEG_ALL(E)                                                                                                  \
     if (vpl == 1) {                                                                                                      \
         switch (lpg) {                                                                                                   \
@@ -1238,7 +1269,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         const int agrid = std::max(1, std::min((total + G - 1) / G, 4096));
         if (t->timing) (void)hipEventRecord(t->ev_t[4][0], st);
 #define CAFE_APPLY(L, V)                                                                                                 \
-    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, t->dim, lr, skip_if_2)
+    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, t->dim, lr, skip_rej, skip_seq)
         if (vpl == 1) {
             switch (lpg) {
                 case 1: CAFE_APPLY(1, 1); break;
@@ -1282,7 +1313,7 @@ extern "C" int cafe_backward_sgd_gid_strided_dev(cafe_tables_t *t, const int32_t
         set_error("cafe_backward_sgd_gid_strided_dev: row stride %d must be a multiple of 4 and at least dim = %d", grad_row_stride, t->dim);
         return 1;
     }
-    return backward_common(t, d_fields, d_que, d_grad_out, 1, n, lr, (hipStream_t)stream, (hipStream_t)stream, 3, nullptr,
+    return backward_common(t, d_fields, d_que, d_grad_out, 1, n, lr, (hipStream_t)stream, (hipStream_t)stream, 3, nullptr, 0,
                            grad_row_stride);
 }
 
@@ -1333,6 +1364,9 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
         const double decay0 = s->decay;
         const int batch_num0 = s->batch_num;
         bool plan_done = false, sums_done = false;
+        // `simple`: a rejected step whose repair must not lean on anything queued earlier -- the forward the caller named
+        // (cafe_forward_hint_dev) was queued behind this step and has reused the update's workspaces -- runs on `st` alone
+        bool simple = false;
         // the update in two kernels when there is a stream to run the first of them beside the insert
         const bool split = side != st && want_split_update(s, t, total);
         if (split && s->opt_split_update != 2 && t->h_rows && (double)t->h_rows[0] > 0.4 * total) {
@@ -1342,7 +1376,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             t->split_pause--;
         }
         for (int attempt = 0; attempt < 2; ++attempt) {
-            if (side != st) {
+            if (side != st && !simple) {
                 // the second stream continues behind the forward that produced this routing (its own completion event),
                 // or, for a routing of unknown origin, behind everything queued on st
                 if (attempt == 0 && s->fwd_que == d_que && s->fwd_que) {
@@ -1376,11 +1410,13 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             s->plan_expect = d_local_ids;
             s->unused_plans = 0;
             if (t->timing) s->ev_chain[0] = t->ev_t[2][0], s->ev_chain[1] = t->ev_t[2][1];
-            const int rc = cafe::insert_dev_on(s, d_gids, gn, psum, nparts, total, d_ins, d_scores, st, (s->opt_overlap & 1) ? side : st);
+            const int rc = cafe::insert_dev_on(s, d_gids, gn, psum, nparts, total, d_ins, d_scores, st,
+                                               (s->opt_overlap & 1) && !simple ? side : st);
+            const uint32_t my_seq = s->call_seq;
             s->seg_len = 0; s->score_seg = 0; s->verify_mode = 0; s->plan_expect = nullptr;
             s->ev_chain[0] = s->ev_chain[1] = nullptr;
             if (rc) return 1;
-            if (side != st && !plan_done) {
+            if (side != st && !plan_done && !simple) {
                 // the partition passes of the update (they read the routing only) beside the insert.  (The row updates
                 // stay behind the migration: a migrated row is copied before it is updated, and hot rows are not disjoint
                 // from migration targets after a reset.  Run beside the insert as a whole, the update slowed the insert's
@@ -1397,8 +1433,20 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
                 }
             }
             if (migrate_list(s, t, d_local_ids, d_gids, d_ins, batch, st)) return 1;
-            if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, sums_done ? s->low_stream : plan_done ? side : st,
-                                sums_done ? 8 : plan_done ? 2 : 3, &s->d_state->fallback)) return 1;
+            if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st,
+                                simple ? st : sums_done ? s->low_stream : plan_done ? side : st,
+                                simple ? 3 : sums_done ? 8 : plan_done ? 2 : 3, &s->d_state->rejected_seq, my_seq)) return 1;
+            // The forward the caller has named as its next call goes in here, before the host waits: the gather behind the
+            // row updates on `st`, its plan behind the commit kernel on the second stream, so the device never waits for
+            // the host between two steps.  Same batch size only (no workspace may grow under the kernels in flight).
+            bool spec = false;
+            cafe_sketch::Hint &h = s->hint;
+            if (attempt == 0 && h.valid && !h.enqueued && h.t == t && h.st == st && h.batch == batch && h.que != d_que &&
+                h.gids != d_gids && s->side_stream) {
+                if (forward_common(s, t, h.ids, nullptr, nullptr, batch, (long)total, h.gids, h.que, h.out, st, true)) return 1;
+                h.enqueued = 1;
+                spec = true;
+            }
             bool rejected = false;
             int reason = 0;
             const double t_wait = now_us();
@@ -1431,6 +1479,23 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
                 return 0;
             }
             if (reason == 4) s->inner_reset_rejects++;
+            if (spec) {
+                // The forward queued ahead read the tables of a step that was not applied, and its plan and partition
+                // passes own the workspaces now: it is dropped (the caller's cafe_forward_dev will run as usual), and the
+                // repair starts behind everything it queued.
+                h.enqueued = 0;
+                s->hint_cancelled++;
+                s->plan_valid = 0;
+                s->fwd_que = nullptr;
+                t->bwd_plan_que = nullptr;
+                CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, s->side_stream));
+                CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));
+                if (s->low_stream) {
+                    CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, s->low_stream));
+                    CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_fork, 0));
+                }
+                simple = true;
+            }
             // nothing was applied on the device: take the call counters back as well
             s->decay = decay0;
             s->batch_num = batch_num0;
@@ -1448,6 +1513,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             if (cafe_insert_dev(s, d_gids + o, d_scores + o, nn, d_ins + o, stream)) return 1;
             if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, cadence ? f : 0, cadence ? 1 : F, stream)) return 1;
         }
+        if (simple) return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, st, 3);
         return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, sums_done ? s->low_stream : side, sums_done ? 8 : 2);
     }
     if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;

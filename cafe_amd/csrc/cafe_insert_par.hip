@@ -2017,6 +2017,7 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
         } else {
             st->why[min(reason, 3) - 1] += reason <= 3 ? 1 : 0;
             st->fallback = 2;
+            st->rejected_seq = A.seq;
             *A.gotcount = 0;
         }
         st->rounds = (int32_t)ctl->final_round;
@@ -2271,7 +2272,8 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     CA.reset_at = s->adjust ? s->lim * 1.2 : 1e300;
     CA.gotcount = w.ctl.as<uint32_t>() + kCtlWords + 2 * (size_t)kMaxParts + 4;
     const int cb = g.P1 + g.P2 + (g.hot ? g.PH : 0);
-    hipLaunchKernelGGL(k_commit, dim3(cb), dim3(256), 0, st, g, CA, sc);
+    // (the kernel's own completion signal is the event a plan made ahead for the NEXT call waits for: no marker packet)
+    hipExtLaunchKernelGGL(k_commit, dim3(cb), dim3(256), 0, st, nullptr, s->ev_commit, 0, g, CA, sc);
     if (s->ev_chain[1]) (void)hipEventRecord(s->ev_chain[1], st);
     CAFE_HIP_CHECK(hipGetLastError());
     s->counters[1]++;

@@ -92,6 +92,20 @@ struct cafe_sketch {
     long long base_clk = 0;             // LRU clock after call base_seq
     int cap_hist[32] = {0};             // largest partition of the last snapshots seen (owner capacity choice)
     uint32_t cap_hist_at = 0, cap_seen_seq = 0, cap_regime_seq = 0;
+    hipEvent_t ev_commit = nullptr;     // completion of the last parallel insert's closing kernel (k_commit)
+    // cafe_forward_hint_dev: the caller has named its next cafe_forward_dev call; cafe_backward_update_dev queues that
+    // forward behind its own kernels BEFORE it waits for the insert's verdict, so the device goes on while the host waits
+    struct Hint {
+        int valid = 0;                  // a next call has been named
+        int enqueued = 0;               // ... and it has been queued (cafe_forward_dev with these arguments returns at once)
+        cafe_tables *t = nullptr;
+        const int64_t *ids = nullptr;
+        int batch = 0;
+        int32_t *gids = nullptr, *que = nullptr;
+        float *out = nullptr;
+        hipStream_t st = nullptr;
+    } hint;
+    int64_t hint_used = 0, hint_cancelled = 0;
     hipEvent_t ev_fwd = nullptr;        // completion of the last cafe_forward_dev gather kernel
     const void *fwd_que = nullptr;      // ... and the routing array it wrote
     uint32_t last_moves = 0;            // moves (LRU -> main) of the newest call the host has a snapshot of

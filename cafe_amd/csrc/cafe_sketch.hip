@@ -389,6 +389,7 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_plan, kDeviceEvent));
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_fwd, kDeviceEvent));
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_gn, kDeviceEvent));
+    CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_commit, kDeviceEvent));
     if (s->ws_misc.reserve(4096)) return 1;
     CAFE_HIP_CHECK(hipMemset(s->d_main, 0, sizeof(MainBucket) * (size_t)s->n1));
     CAFE_HIP_CHECK(hipMemset(s->d_lru, 0, sizeof(LruBucket) * (size_t)s->n2));
@@ -413,6 +414,7 @@ extern "C" int cafe_sketch_destroy(cafe_sketch_t *s) {
     if (s->ev_head_join) (void)hipEventDestroy(s->ev_head_join);
     if (s->ev_plan) (void)hipEventDestroy(s->ev_plan);
     if (s->ev_fwd) (void)hipEventDestroy(s->ev_fwd);
+    if (s->ev_commit) (void)hipEventDestroy(s->ev_commit);
     s->ws_reset_keys.release(); s->ws_reset_keys2.release(); s->ws_reset_tmp.release();
     s->ws_reset_flags.release(); s->ws_misc.release();
     delete s;

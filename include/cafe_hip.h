@@ -155,6 +155,20 @@ int cafe_tables_kernel_ms(cafe_tables_t *t, int which, float *ms);
 int cafe_forward_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, int batch,
                      int32_t *d_gids, int32_t *d_que, float *d_out, cafe_stream_t stream);
 
+/* No counterpart in the reference (its loop is synchronous on the host).  Names the caller's NEXT cafe_forward_dev call
+ * -- the same eight arguments -- typically the batch a data loader has already delivered.  The following
+ * cafe_backward_update_dev on the same stream queues that forward (gather, plan of the next insert, partition passes)
+ * behind its own kernels BEFORE it waits for the device's verdict, so the device never idles while the host waits and
+ * returns; the announced cafe_forward_dev call then finds its work queued and returns at once.  Results are exactly
+ * those of the plain call order: if the step is rejected and issued again, the queued forward is dropped and the
+ * announced call runs as usual.  Requirements: d_gids / d_que of the announced call must not be the arrays the pending
+ * update reads (alternate two sets), the batch size must equal the current step's, and the ids must be complete in
+ * memory when the hint is given.  A hint that is not followed by the announced call is forgotten. */
+int cafe_forward_hint_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, int batch,
+                          int32_t *d_gids, int32_t *d_que, float *d_out, cafe_stream_t stream);
+/* out2[0] = announced forwards that were found queued, out2[1] = queued forwards dropped because their step was rejected. */
+int cafe_forward_hint_stats(cafe_sketch_t *s, int64_t *out2);
+
 /* sketch_ml_embed.py:154-199, the three-tier forward, in one launch: as cafe_forward_dev, plus
  * d_qmed out [num_fields*batch] = batch_query_median of d_gids, and a cold lookup of medium importance adds
  * d_w_median[gid % median_n] ([median_n, dim] float32, shared by all fields like the hot table) to its cold row. */

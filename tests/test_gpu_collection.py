@@ -63,9 +63,9 @@ def test_collection_steps_match_oracle(dim, per_field, oracle_mod):
 
 
 
-@pytest.mark.parametrize("alpha,steps,verify,exact", [(1.0000005, 420, 1, 0), (1.0000005, 420, 0, 0), (1.1, 150, 1, 0),
-                                                      (1.0000005, 300, 1, 1)])
-def test_one_insert_per_step_keeps_the_per_field_cadence(alpha, steps, verify, exact, oracle_mod):
+@pytest.mark.parametrize("alpha,steps,verify,exact,hint", [(1.0000005, 420, 1, 0, 0), (1.0000005, 420, 0, 0, 0), (1.1, 150, 1, 0, 0),
+                                                           (1.0000005, 300, 1, 1, 0), (1.0000005, 420, 1, 0, 1), (1.1, 150, 1, 0, 1)])
+def test_one_insert_per_step_keeps_the_per_field_cadence(alpha, steps, verify, exact, hint, oracle_mod):
     """cafe_backward_update_dev(per_field=1) runs a step as ONE parallel insert whenever no flip and no reset can fall
     between two fields, and field by field otherwise; either way the sketch must be what the reference's loop over
     fields leaves (one batch_insert_val per field: decay, batch counter and the reset test per field).  Long enough
@@ -73,7 +73,10 @@ def test_one_insert_per_step_keeps_the_per_field_cadence(alpha, steps, verify, e
     calls; after the first one Threshold <= 1, the regime of SURVEY Q3, where steps are issued field by field).
     verify = 1: steps that MAY hold a reset boundary still run as one insert that the device rejects, before
     committing anything, when a boundary fires (the host then issues the step field by field); 0: such steps are
-    issued field by field from the start.  Bit-exact: ins[], every slot, scalars, free list; tables within 1e-5."""
+    issued field by field from the start.  Bit-exact: ins[], every slot, scalars, free list; tables within 1e-5.
+    hint = 1: every step names the next one's ids (cafe_forward_hint_dev), so the next forward is queued before the
+    verdict is known -- and dropped and run again behind the repair whenever a step is rejected; the forward's
+    routing and rows are compared every step."""
     from cafe_amd.collection import CafeEmbeddingCollection
     counts = [30000, 4000, 90000, 700]
     hash_sizes = [97, 13, 301, 5]
@@ -85,12 +88,25 @@ def test_one_insert_per_step_keeps_the_per_field_cadence(alpha, steps, verify, e
     rng = np.random.default_rng(21)
     F = len(counts)
     gen = torch.Generator(device="cuda").manual_seed(4)
-    for step in range(steps):
+
+    def draw(step):
         # the head of the Zipf law drifts, so new ids keep crossing the threshold and resets keep coming
         ids = np.stack([(rng.zipf(1.2, size=B) - 1 + step * 5) % c for c in counts]).astype(np.int64)
         ids[0] = np.maximum(ids[0], 1)
-        coll.forward(torch.from_numpy(ids).cuda())
-        cpu.forward(ids)
+        return ids, torch.from_numpy(ids).cuda()
+
+    outs = [torch.empty(F, B, dim, device="cuda") for _ in range(2)]
+    nxt = draw(0)
+    for step in range(steps):
+        ids, d_ids = nxt
+        out = coll.forward(d_ids, out=outs[step % 2])
+        want = cpu.forward(ids)
+        if hint:
+            assert np.array_equal(coll._buf["que"].cpu().numpy().reshape(F, B), np.stack(cpu.que)), f"step {step}: routing"
+            _close(out.cpu().numpy(), want, f"step {step} forward")
+        nxt = draw(step + 1)
+        if hint:
+            coll.hint_next(nxt[1], outs[(step + 1) % 2])
         grad = torch.randn(F, B, dim, device="cuda", generator=gen)
         scores, ins = coll.backward_update(grad, lr, per_field_calls=True)
         sc = scores.cpu().numpy().reshape(F, B)
@@ -102,6 +118,9 @@ def test_one_insert_per_step_keeps_the_per_field_cadence(alpha, steps, verify, e
     c = coll.sketch.counters()
     st = coll.sketch.state()
     assert c["cadence_miss"] == 0
+    if hint:
+        used, dropped = coll.hint_stats()
+        assert used > 5 and (dropped > 0 or alpha > 1.001), (used, dropped)
     assert c["insert_calls"] < steps * F, "no step ran as one insert"
     if alpha < 1.001:
         assert st["resets"] >= (1 if exact else 2), st["resets"]
@@ -164,15 +183,23 @@ def test_pairings_the_reference_would_alias_are_refused():
         CafeEmbeddingCollection([10, 10], 16, 50, [5, 5], offsets=[0, 2 ** 31], threshold=2)
 
 
-def _run_steps(coll, cpu, oracle_mod, batches, grads, lr=0.05, check_tables=True):
-    """forward + backward_update(per_field) on both sides; ins[] compared every step, state and tables at the end."""
+def _run_steps(coll, cpu, oracle_mod, batches, grads, lr=0.05, check_tables=True, hint=False):
+    """forward + backward_update(per_field) on both sides; ins[] compared every step, state and tables at the end.
+    hint: every step names the next one's ids before its update (the next forward is queued ahead of the verdict)."""
     F = coll.F
     deltas = []
+    d_batches = [torch.from_numpy(ids).cuda() for ids in batches]
+    outs = [torch.empty(F, batches[0].shape[1], coll.dim, device="cuda") for _ in range(2)]
     for step, (ids, grad) in enumerate(zip(batches, grads)):
         B = ids.shape[1]
         before = cpu.sk.state()["real_n"]
-        coll.forward(torch.from_numpy(ids).cuda())
-        cpu.forward(ids)
+        out = coll.forward(d_batches[step], out=outs[step % 2])
+        want = cpu.forward(ids)
+        if hint:
+            assert np.array_equal(coll._buf["que"].cpu().numpy().reshape(F, B), np.stack(cpu.que)), f"step {step}: routing"
+            _close(out.cpu().numpy(), want, f"step {step} forward")
+            if step + 1 < len(batches):
+                coll.hint_next(d_batches[step + 1], outs[(step + 1) % 2])
         scores, ins = coll.backward_update(grad, lr, per_field_calls=True)
         sc = scores.cpu().numpy().reshape(F, B)
         ins_want = cpu.backward_update(ids, grad.cpu().numpy(), sc, lr, True)
@@ -242,13 +269,14 @@ def test_crossing_burst_fires_the_reset_at_an_inner_field_boundary(split_update,
         _run_steps(coll, cpu, oracle_mod, *[[x] for x in batch(5)])
 
 
+@pytest.mark.parametrize("hint", [False, True], ids=["plain", "next_forward_queued_ahead"])
 @pytest.mark.parametrize("B", [2048, 8192], ids=["one_stream", "split_update"])
 @pytest.mark.parametrize("option,value,reason,hotn", [
     ("max_rounds", 1, "rounds_not_settled", 1200),
     ("move_cap", 1, "workspace_limit", 1200),
     (None, 0, "free_list", 150),
 ], ids=["rounds", "move_list", "free_list"])
-def test_fused_steps_that_the_device_rejects_stay_exact(option, value, reason, hotn, B, oracle_mod):
+def test_fused_steps_that_the_device_rejects_stay_exact(option, value, reason, hotn, B, hint, oracle_mod):
     """every reason for leaving the parallel path, forced inside fused steps (the device rejects the
     step before applying anything; the host issues it again with the largest owners, then call by call): too few
     rounds enqueued, the move list of a main partition full, the free list running dry inside the batch.  B = 8192
@@ -273,7 +301,10 @@ def test_fused_steps_that_the_device_rejects_stay_exact(option, value, reason, h
         g = torch.randn(F, B, dim, device="cuda", generator=gen)
         g[:, ::3] *= 8.0                      # large scores: evicted LRU entries qualify for a move (sketch.cpp:193-195)
         batches.append(ids); grads.append(g)
-    _run_steps(coll, cpu, oracle_mod, batches, grads)
+    _run_steps(coll, cpu, oracle_mod, batches, grads, hint=hint)
     c = coll.sketch.counters()
+    if hint:
+        used, dropped = coll.hint_stats()
+        assert dropped > 0, (used, dropped)      # forwards queued ahead were dropped behind rejected steps
     assert c["left_parallel_path"][reason] > 0, c
     assert c["cadence_miss"] == 0

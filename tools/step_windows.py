@@ -42,26 +42,40 @@ def read():
 
 
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+hint = os.environ.get("HINT", "1") == "1"
+
+
+def step(i):
+    eng.forward(ids[i % 16], out=out)
+    if hint:
+        eng.hint_next(ids[(i + 1) % 16], out)
+    eng.backward_update(grad, 0.1, per_field_calls=True)
+
+
+import time
 for i in range(n):
-    eng.forward(ids[i % 16], out=out); eng.backward_update(grad, 0.1, per_field_calls=True)
+    step(i)
 torch.cuda.synchronize()
 for rep in range(3):
     # a run of steps without a host synchronisation; every kernel's stamps are those of its last launch
+    t0 = time.perf_counter()
     for i in range(40):
-        eng.forward(ids[(n + i) % 16], out=out); eng.backward_update(grad, 0.1, per_field_calls=True)
+        step(n + i)
     n += 40
     torch.cuda.synchronize()
+    period = (time.perf_counter() - t0) / 40 * 1e6
     w = read()
-    start_last = w["k_forward"][:, 0][w["k_forward"][:, 0] > 0].min()        # the forward's grid is the same every step
+    # origin: the norm kernel of the last step.  With hints the forward queued behind that step (and its plan) shows up
+    # behind the row updates; without, the last step's own forward lies before the origin and is listed with its offset.
+    gn = w["k_grad_norm"]
+    origin = gn[:, 0][gn[:, 0] > 0].min()
     rows = []
     for nm, b in w.items():
-        ok = (b[:, 0] >= start_last) & (b[:, 1] > 0)
+        ok = (b[:, 0] >= origin - 6000) & (b[:, 1] > 0)
         if ok.any():
             rows.append((b[ok, 0].min(), b[ok, 1].max(), nm, int(ok.sum()), np.median(b[ok, 1] - b[ok, 0]) / 100.0))
     rows.sort()
-    base = rows[0][0]
-    print(f"step timeline (us from the first workgroup of k_forward), {wl.name}:")
+    print(f"step timeline (us from the first workgroup of k_grad_norm), {wl.name}, hint={int(hint)}, period {period:.1f} us/step:")
     for s, e, nm, cnt, med in rows:
-        print(f"  {nm:16s} wgs={cnt:5d} start={(s - base) / 100:7.1f} end={(e - base) / 100:7.1f} dur={(e - s) / 100:6.1f}  median wg {med:6.1f}")
-    print(f"  last exit at {(max(r[1] for r in rows) - base) / 100:.1f} us")
+        print(f"  {nm:16s} wgs={cnt:5d} start={(s - origin) / 100:7.1f} end={(e - origin) / 100:7.1f} dur={(e - s) / 100:6.1f}  median wg {med:6.1f}")
 print(eng.sketch.counters())
