@@ -140,12 +140,19 @@ __device__ inline void load_main(MainR &b, const MainBucket *src) {
     b.flip = src->flip;
 }
 // `tag` goes to pad[0]: unused in the tables, the bucket index in the staging copies of the parallel insert
-__device__ inline void store_main(MainBucket *dst, const MainR &b, int32_t tag = 0) {
+// `keep` goes to pad[1] (staging copies only): mask of the slots whose score the commit must leave alone
+__device__ inline void store_main(MainBucket *dst, const MainR &b, int32_t tag = 0, int32_t keep = 0) {
     int4 *p = reinterpret_cast<int4 *>(dst);
     p[0] = make_int4(b.v0, b.v1, b.v2, b.v3);
     p[1] = make_int4(b.d0, b.d1, b.d2, b.d3);
     p[2] = make_int4(__float_as_int(b.c0), __float_as_int(b.c1), __float_as_int(b.c2), __float_as_int(b.c3));
-    p[3] = make_int4((int)b.flip, tag, 0, 0);
+    p[3] = make_int4((int)b.flip, tag, keep, 0);
+}
+// slots that sit hot in a bucket whose lazy decay is not pending: their items went through the hot bypass of the
+// parallel insert, which owns their scores
+__device__ inline int32_t hot_keep_mask(const MainR &b, uint32_t gflip) {
+    if (b.flip != gflip) return 0;
+    return (b.d0 ? 1 : 0) | (b.d1 ? 2 : 0) | (b.d2 ? 4 : 0) | (b.d3 ? 8 : 0);
 }
 __device__ inline void load_lru(LruR &b, const LruBucket *src) {
     const int4 *p = reinterpret_cast<const int4 *>(src);

@@ -1220,9 +1220,11 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     if (!(part & 14)) { CAFE_HIP_CHECK(hipGetLastError()); return 0; }
     const int grid = max_tiles;
     const int gs = gstride ? gstride : t->dim;
-    // the gradient pass of the split form shares the device with the insert's kernels: a persistent grid of six
-    // workgroups per compute unit (1024 .. 2560 measured within 1 % of each other on cfg3)
-    static const int emit_grid = getenv("CAFE_EMIT_GRID") ? atoi(getenv("CAFE_EMIT_GRID")) : 1536;
+    // the gradient pass of the split form shares the device with the insert's kernels: a persistent grid of four
+    // workgroups per compute unit (1024 .. 2560 measured within 1 % of each other on cfg3).  Four, at 96 vector registers
+    // a lane, leave every compute unit room for one workgroup of the insert's persistent tail kernel (128 registers),
+    // whose grid barriers need all of its workgroups resident.
+    static const int emit_grid = getenv("CAFE_EMIT_GRID") ? atoi(getenv("CAFE_EMIT_GRID")) : 1024;
 #define CAFE_SEG(L, V, E)                                                                                                \
     hipLaunchKernelGGL((k_bwd_segments<L, V, E>), dim3(E ? std::min(grid, emit_grid) : grid), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
                        t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_rej, skip_seq, gs, entries, sums)
@@ -1410,9 +1412,14 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             s->plan_expect = d_local_ids;
             s->unused_plans = 0;
             if (t->timing) s->ev_chain[0] = t->ev_t[2][0], s->ev_chain[1] = t->ev_t[2][1];
+            // the insert's commit copies the rows of the ids that take a slot itself (sk_embedding_bag.py:199-208)
+            s->mig.w_hot = t->d_w_hot; s->mig.w_cold = t->d_w_cold; s->mig.hash_size = t->d_hash_size; s->mig.local_ids = d_local_ids;
+            s->mig.batch = batch; s->mig.dim = t->dim; s->mig.hotn = t->hotn;
+            s->mig_done = 0;
             const int rc = cafe::insert_dev_on(s, d_gids, gn, psum, nparts, total, d_ins, d_scores, st,
                                                (s->opt_overlap & 1) && !simple ? side : st);
             const uint32_t my_seq = s->call_seq;
+            s->mig.w_hot = nullptr;
             s->seg_len = 0; s->score_seg = 0; s->verify_mode = 0; s->plan_expect = nullptr;
             s->ev_chain[0] = s->ev_chain[1] = nullptr;
             if (rc) return 1;
@@ -1432,7 +1439,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
                     sums_done = true;
                 }
             }
-            if (migrate_list(s, t, d_local_ids, d_gids, d_ins, batch, st)) return 1;
+            if (!s->mig_done && migrate_list(s, t, d_local_ids, d_gids, d_ins, batch, st)) return 1;
             if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st,
                                 simple ? st : sums_done ? s->low_stream : plan_done ? side : st,
                                 simple ? 3 : sums_done ? 8 : plan_done ? 2 : 3, &s->d_state->rejected_seq, my_seq)) return 1;

@@ -1139,6 +1139,7 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
         if (nmode == 1) load_main(nb, &A.mt[b0 + (int)L.s.sg[s + kThreads]]);
         if (mode != 1) continue;
         const uint32_t bl = L.s.sg[s];
+        const int32_t keep = hot_keep_mask(b, gflip);
         sync_flip(b, gflip);
         for (int e = s; e < total && L.s.sg[e] == bl; ++e) {
             const uint32_t time = L.s.stm[e];
@@ -1159,7 +1160,7 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
                 A.evres[time >> 1] = r;
             }
         }
-        store_main(&stage[s], b, b0 + (int)bl);
+        store_main(&stage[s], b, b0 + (int)bl, keep);
     }
     __syncthreads();
     CAFE_STAMP(g.prof, 4);
@@ -1177,6 +1178,7 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
             const uint32_t bl = L.s.sg[s];
             MainR b = nhb;
             if (h + kWaves < nh) load_main(nhb, &A.mt[b0 + (int)L.s.sg[heavy[h + kWaves]]]);
+            const int32_t keep = hot_keep_mask(b, gflip);
             sync_flip(b, gflip);
             int e = s;
             while (e < total && L.s.sg[e] == bl) {
@@ -1285,7 +1287,7 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
                     e += 1;
                 }
             }
-            if (lane == 0) store_main(&stage[s], b, b0 + (int)bl);
+            if (lane == 0) store_main(&stage[s], b, b0 + (int)bl, keep);
         }
     }
     __syncthreads();
@@ -1593,11 +1595,16 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(C
 // rounds >= 2: one persistent grid of kFixGrid workgroups
 // ------------------------------------------------------------------------------------------------
 // Grid-wide barrier (monotonic counter, MI355X_MICROARCH.md "barrier-counter"): every workgroup's stores are released
-// at agent scope before it arrives and the CU's L1 is invalidated after the wait.  All kFixGrid workgroups are
-// resident (one per CU suffices), and the wait is bounded: a barrier that does not complete flags the batch as
-// unsettled, which every workgroup reads behind the same barrier call.
-__device__ inline bool grid_barrier(Ctl *ctl, uint32_t &gen) {
-    __shared__ int ok;
+// at agent scope before it arrives and the CU's L1 is invalidated after the wait.  The last arriver also samples the
+// control words every workgroup is about to branch on (a workspace limit, "the miss set changed in round r") and
+// publishes them WITH the generation: all workgroups act on the same latched value, so none can leave a round that
+// another one still enters (read after the barrier, such a flag could be raised meanwhile by a workgroup that is already
+// in the next half-round: one workgroup would return, the others would wait for it at the next barrier).  All workgroups
+// are resident (the kernel keeps to 128 vector registers, which the gradient pass of a split update leaves free on every
+// compute unit); the wait is bounded as a safety net: a barrier that does not complete flags the batch as unsettled.
+constexpr uint32_t kLatchOver = 1u << 30, kLatchChanged = 1u << 31, kGenMask = (1u << 30) - 1u;
+__device__ inline uint32_t grid_barrier(Ctl *ctl, uint32_t &gen, int sample_round) {
+    __shared__ uint32_t latched;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1605,27 +1612,36 @@ __device__ inline bool grid_barrier(Ctl *ctl, uint32_t &gen) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t target = (gen + 1u) * gridDim.x;
         const uint32_t arrived = __hip_atomic_fetch_add(&ctl->bar_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        int good = 1;
+        uint32_t word;
         if (arrived == target) {
-            __hip_atomic_store(&ctl->bar_gen, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // everything the other workgroups wrote before they arrived is visible behind this fence
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            word = gen + 1u;
+            if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) word |= kLatchOver;
+            if (sample_round > 0 && __hip_atomic_load(&ctl->changed[sample_round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) word |= kLatchChanged;
+            __hip_atomic_store(&ctl->bar_gen, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             long spins = 0;
-            while (__hip_atomic_load(&ctl->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen + 1u) {
+            while (((word = __hip_atomic_load(&ctl->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kGenMask) < gen + 1u) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1L << 24)) { good = 0; break; }
+                if (++spins > (1L << 24)) {           // never seen: k_finish / k_commit then refuse the batch
+                    __hip_atomic_store(&ctl->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    word = (gen + 1u) | kLatchOver;
+                    break;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ok = good;
+        latched = word;
     }
     __syncthreads();
     gen += 1u;
-    return ok != 0;
+    return latched;
 }
 
 template <int CAP>
-__global__ void __launch_bounds__(kThreads) k_fix(Geo g, MainArgs MA, LruArgs LA, Score sc) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CAP <= 2048 ? 4 : 1, 8))) k_fix(Geo g, MainArgs MA, LruArgs LA, Score sc) {
     CAFE_KWIN(4);
     g.prof = 5;
     __shared__ __attribute__((aligned(16))) OwnerLds<CAP, true> L;
@@ -1656,10 +1672,10 @@ __global__ void __launch_bounds__(kThreads) k_fix(Geo g, MainArgs MA, LruArgs LA
             ran += 1;
         }
         CAFE_STAMP(pslot, 1);
-        if (!grid_barrier(ctl, gen)) { if (tid == 0) ctl->overflow = 1; return; }
+        uint32_t latch = grid_barrier(ctl, gen, round);
         CAFE_STAMP(pslot, 2);
-        if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-        if (!__hip_atomic_load(&ctl->changed[round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        if (latch & kLatchOver) return;
+        if (!(latch & kLatchChanged)) {
             if (blockIdx.x == 0 && tid == 0) ctl->final_round = (uint32_t)round;
             CAFE_STAMP_VAL(pslot, 5, ran);
             return;
@@ -1673,10 +1689,10 @@ __global__ void __launch_bounds__(kThreads) k_fix(Geo g, MainArgs MA, LruArgs LA
             ran += 1ull << 16;
         }
         CAFE_STAMP(pslot, 3);
-        if (!grid_barrier(ctl, gen)) { if (tid == 0) ctl->overflow = 1; return; }
+        latch = grid_barrier(ctl, gen, 0);
         CAFE_STAMP(pslot, 4);
         CAFE_STAMP_VAL(pslot, 5, ran);
-        if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (latch & kLatchOver) return;
     }
 }
 
@@ -1686,19 +1702,23 @@ __global__ void __launch_bounds__(kThreads) k_fix(Geo g, MainArgs MA, LruArgs LA
 // Per item: final outcome (ins[]), whether it pops / pushes / ticks the LRU clock, and the exclusive ranks of those
 // three events in batch order.  Workgroups publish their totals as two self-tagged 8-byte words and sum the words of
 // the workgroups in front of them (decoupled look-back: a workgroup only ever waits for lower-numbered ones).
-__global__ void __launch_bounds__(kScanBlock) k_finish(
+// A workgroup of 256 lanes takes kScanBlock = 1024 consecutive items, four chunks of 256: the whole grid (one workgroup
+// per 1024 items, four waves of ~100 registers) is resident at once even beside the gradient pass of a split update,
+// and everything a lane needs from memory is requested before any of it is looked at.
+constexpr int kFinI = kScanBlock / kThreads;
+__global__ void __launch_bounds__(kThreads) k_finish(
     Geo g, unsigned long long call_tag, Ctl *ctl, const uint8_t *__restrict__ miss, const uint8_t *__restrict__ outm,
     const uint8_t *__restrict__ outl, const EvRes *__restrict__ evres, int32_t *__restrict__ ins, uint8_t *__restrict__ flags,
     int32_t *__restrict__ pushval, unsigned long long *agg /* [nblocks][2] */, uint32_t *__restrict__ poprank,
     uint32_t *__restrict__ pushrank, uint32_t *__restrict__ clkrank, uint32_t *__restrict__ gotlist, Score sc,
     float *__restrict__ scores_out) {
     CAFE_KWIN(5);
-    __shared__ uint32_t wsum[3][kScanBlock / 64];
+    __shared__ uint32_t wsum[kFinI][3][kWaves];
     __shared__ uint32_t s_cross;
     __shared__ uint32_t s_base[4];
     __shared__ float fsum[kMaxSeg];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int i = blockIdx.x * kScanBlock + tid;
+    const int base = blockIdx.x * kScanBlock;
     CAFE_STAMP(1, 0);
     // the scores as every owner formed them, for the caller (sk_embedding_bag.py:189): written whatever the verdict, but
     // AFTER this workgroup has published its totals -- the workgroups behind it wait for those, not for the scores
@@ -1707,45 +1727,71 @@ __global__ void __launch_bounds__(kScanBlock) k_finish(
         field_sums(g, sc, fsum);
         __syncthreads();
         const ScoreSrc ss = score_src(g, sc, fsum);
-        if (i < g.n) scores_out[i] = ss.at((uint32_t)i);
+#pragma unroll
+        for (int j = 0; j < kFinI; ++j) {
+            const int i = base + j * kThreads + tid;
+            if (i < g.n) scores_out[i] = ss.at((uint32_t)i);
+        }
     };
     CAFE_STAMP(1, 1);
     const bool live = !ctl->overflow && ctl->final_round != 0;
     if (!live) { write_scores(); return; }             // uniform; k_commit decides what happens to the batch
     if (tid == 0) s_cross = 0;
-    uint32_t pop = 0, push = 0, clk = 0, cross = 0;
-    if (i < g.n) {
-        const uint8_t m = miss[i];
-        const uint8_t o = m ? outl[i] : outm[i];
-        int got = (o & oGot) ? 1 : 0;
-        pop = (o & oPop) ? 1 : 0;
-        cross = (o & oCross) ? 1 : 0;
-        clk = m ? 1 : 0;
-        int32_t pv = 0;
-        if (m && (o & oEv)) {
-            const EvRes r = evres[i];
-            if (r.tag == call_tag) {
-                if (r.kind == 1 && !r.ok) got = 0;           // sketch.cpp:180-182
-                if (!r.ok && r.pushed != 0) { push = 1; pv = r.pushed; }
+    uint8_t mm[kFinI], om[kFinI], ol[kFinI];
+#pragma unroll
+    for (int j = 0; j < kFinI; ++j) {
+        const int i = base + j * kThreads + tid;
+        const bool in = i < g.n;
+        mm[j] = in ? miss[i] : 0; om[j] = in ? outm[i] : 0; ol[j] = in ? outl[i] : 0;
+    }
+    EvRes er[kFinI];
+#pragma unroll
+    for (int j = 0; j < kFinI; ++j) {
+        const int i = base + j * kThreads + tid;
+        er[j].tag = 0; er[j].kind = 0; er[j].ok = 1; er[j].pushed = 0;
+        if (i < g.n && mm[j] && (ol[j] & oEv)) er[j] = evres[i];
+    }
+    unsigned long long m0[kFinI], m1[kFinI], m2[kFinI];
+    uint32_t ncross = 0;
+#pragma unroll
+    for (int j = 0; j < kFinI; ++j) {
+        const int i = base + j * kThreads + tid;
+        uint32_t pop = 0, push = 0, clk = 0, cross = 0;
+        if (i < g.n) {
+            const uint8_t m = mm[j];
+            const uint8_t o = m ? ol[j] : om[j];
+            int got = (o & oGot) ? 1 : 0;
+            pop = (o & oPop) ? 1 : 0;
+            cross = (o & oCross) ? 1 : 0;
+            clk = m ? 1 : 0;
+            int32_t pv = 0;
+            if (m && (o & oEv) && er[j].tag == call_tag) {
+                if (er[j].kind == 1 && !er[j].ok) got = 0;           // sketch.cpp:180-182
+                if (!er[j].ok && er[j].pushed != 0) { push = 1; pv = er[j].pushed; }
             }
+            ins[i] = got;
+            pushval[i] = pv;
+            flags[i] = (uint8_t)(pop | (push << 1) | (clk << 2));
+            if (cross && g.seg > 0) atomicAdd(&ctl->segcross[i / g.seg], 1u);      // a few hundred per call
+            if (got) gotlist[atomicAdd(&ctl->ngot, 1u)] = (uint32_t)i;
         }
-        ins[i] = got;
-        pushval[i] = pv;
-        flags[i] = (uint8_t)(pop | (push << 1) | (clk << 2));
-        if (cross && g.seg > 0) atomicAdd(&ctl->segcross[i / g.seg], 1u);      // a few hundred per call
-        if (got) gotlist[atomicAdd(&ctl->ngot, 1u)] = (uint32_t)i;
+        m0[j] = __ballot(pop); m1[j] = __ballot(push); m2[j] = __ballot(clk);
+        ncross += (uint32_t)__popcll(__ballot(cross));
+        if (lane == 0) { wsum[j][0][w] = __popcll(m0[j]); wsum[j][1][w] = __popcll(m1[j]); wsum[j][2][w] = __popcll(m2[j]); }
     }
     CAFE_STAMP(1, 2);
     const unsigned long long below = lanes_below();
-    const unsigned long long m0 = __ballot(pop), m1 = __ballot(push), m2 = __ballot(clk), mx = __ballot(cross);
-    if (lane == 0) { wsum[0][w] = __popcll(m0); wsum[1][w] = __popcll(m1); wsum[2][w] = __popcll(m2); }
     __syncthreads();
-    if (lane == 0 && mx) atomicAdd(&s_cross, (uint32_t)__popcll(mx));
-    uint32_t t0 = 0, t1 = 0, t2 = 0, b0 = 0, b1 = 0, b2 = 0;
-    for (int k = 0; k < kScanBlock / 64; ++k) {
-        if (k == w) { b0 = t0; b1 = t1; b2 = t2; }
-        t0 += wsum[0][k]; t1 += wsum[1][k]; t2 += wsum[2][k];
-    }
+    if (lane == 0 && ncross) atomicAdd(&s_cross, ncross);
+    // exclusive prefix of this lane's chunk/wave among the workgroup's (chunk, wave) pairs, in batch order
+    uint32_t t0 = 0, t1 = 0, t2 = 0, b0[kFinI], b1[kFinI], b2[kFinI];
+#pragma unroll
+    for (int j = 0; j < kFinI; ++j)
+#pragma unroll
+        for (int k = 0; k < kWaves; ++k) {
+            if (k == w) { b0[j] = t0; b1[j] = t1; b2[j] = t2; }
+            t0 += wsum[j][0][k]; t1 += wsum[j][1][k]; t2 += wsum[j][2][k];
+        }
     __syncthreads();
     // publish this workgroup's totals, then sum the words in front of it: a lane per workgroup in front, all waves at once
     if (tid == 0) {
@@ -1757,7 +1803,7 @@ __global__ void __launch_bounds__(kScanBlock) k_finish(
     __syncthreads();
     {
         unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int bq = (int)blockIdx.x - 1 - tid; bq >= 0; bq -= kScanBlock) {
+        for (int bq = (int)blockIdx.x - 1 - tid; bq >= 0; bq -= kThreads) {
             unsigned long long v0 = __hip_atomic_load(&agg[2 * bq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned long long v1 = __hip_atomic_load(&agg[2 * bq + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             long spins = 0;
@@ -1778,10 +1824,14 @@ __global__ void __launch_bounds__(kScanBlock) k_finish(
     }
     __syncthreads();
     CAFE_STAMP(1, 3);
-    if (i < g.n) {
-        poprank[i] = s_base[0] + b0 + (uint32_t)__popcll(m0 & below);
-        pushrank[i] = s_base[1] + b1 + (uint32_t)__popcll(m1 & below);
-        clkrank[i] = s_base[2] + b2 + (uint32_t)__popcll(m2 & below);
+#pragma unroll
+    for (int j = 0; j < kFinI; ++j) {
+        const int i = base + j * kThreads + tid;
+        if (i < g.n) {
+            poprank[i] = s_base[0] + b0[j] + (uint32_t)__popcll(m0[j] & below);
+            pushrank[i] = s_base[1] + b1[j] + (uint32_t)__popcll(m1[j] & below);
+            clkrank[i] = s_base[2] + b2[j] + (uint32_t)__popcll(m2[j] & below);
+        }
     }
     // the last workgroup's sums are the batch totals (no contended atomics: 200 workgroups adding to one line cost ~10 us)
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
@@ -1824,6 +1874,13 @@ struct CommitArgs {
     uint32_t seq;
     double reset_at;
     uint32_t *gotcount;         // what the migration kernel reads: number of got-list entries, 0xffffffff = scan ins[]
+    // migration of the ids that took a slot (sk_embedding_bag.py:199-208), done by the lane that commits their bucket;
+    // w_hot == nullptr: none (the caller migrates by itself)
+    float *w_hot;
+    float *const *w_cold;
+    const int32_t *hash_size;
+    const int64_t *local_ids;
+    int batch, dim, hotn;
 };
 
 // commit: decision; staged buckets -> tables with placeholders resolved; pushes -> free list; the workgroup that
@@ -1841,7 +1898,6 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
     // together with the words of the decision, not behind it (none of them changes before the last workgroup is done)
     const uint32_t head = st->fifo_head, len0 = st->fifo_len;
     const int32_t clk0 = st->clk;
-    const uint32_t gflip = (uint32_t)st->flip;
     const int part_mine = blockIdx.x;
     int tot_mine = 0;
     uint32_t offa_mine = 0, offb_mine = 0;
@@ -1876,6 +1932,31 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
     const int verdict = s_verdict;
     CAFE_STAMP(2, 1);
     if (verdict == 0) {
+        // A slot this batch handed out sits in a staged main bucket as a placeholder: the lane that resolves it also
+        // copies the row of the id that took it from its cold table -- the PRE-update row under the LOCAL id
+        // (sk_embedding_bag.py:205-208; the row updates run behind this kernel).  An id that popped a slot
+        // ends up in the main table with that slot exactly when the reference reports ins != 0 and its re-query reads
+        // hot: a slot popped on a main hit stays where it is (hot slots are never replaced, sketch.cpp:253-258); one
+        // popped in the LRU table arrives with its entry's move, or is pushed back when that move fails (ins cleared,
+        // sketch.cpp:180-182); one that stays in the LRU table is not hot for query() (SURVEY Q3 fence).
+        // The copy itself is the wave's: the lanes that found a placeholder are taken one after the other, and all 64
+        // lanes move that row (one memory round trip per row instead of one per 16 bytes).
+        const int dim4 = A.dim >> 2;
+        const int lane = tid & 63;
+        auto migrate_wave = [&](int32_t placeholder, int32_t slot) {          // called by all lanes of the wave
+            unsigned long long mk = __ballot(A.w_hot != nullptr && ((uint32_t)placeholder & kSur) && slot > 0);
+            while (mk) {
+                const int l = __builtin_ctzll(mk);
+                mk &= mk - 1ull;
+                const uint32_t pos = (uint32_t)__shfl(placeholder, l, 64) & ~kSur;
+                const uint32_t sl = (uint32_t)__shfl(slot, l, 64);
+                const int f = (int)(pos / (uint32_t)A.batch);
+                const int64_t src_row = A.local_ids[pos] % (int64_t)A.hash_size[f];
+                const float4 *src = reinterpret_cast<const float4 *>(A.w_cold[f] + (size_t)src_row * A.dim);
+                float4 *dst = reinterpret_cast<float4 *>(A.w_hot + (size_t)(sl % (uint32_t)A.hotn) * A.dim);
+                for (int c = lane; c < dim4; c += 64) dst[c] = src[c];
+            }
+        };
         const int nparts = g.P1 + g.P2 + (g.hot ? g.PH : 0);
         for (int part = blockIdx.x; part < nparts; part += gridDim.x) {
             const bool mine = part == part_mine;
@@ -1900,34 +1981,39 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
             if (tot < 0 || tot > room) { if (tid == 0) atomicAdd(&st->bad_commit, 1); tot = 0; }
             if (part < g.P1) {
                 const MainBucket *stage = A.stage_m + offa + (size_t)part * g.evs;
-                for (int s = tid; s < tot; s += blockDim.x) {
-                    const int4 *p = reinterpret_cast<const int4 *>(&stage[s]);
+                for (int sb = 0; sb < tot; sb += blockDim.x) {           // uniform: every lane of a wave reaches the migration
+                    const int s = sb + tid;
+                    bool on = s < tot;
+                    const int4 *p = reinterpret_cast<const int4 *>(&stage[on ? s : 0]);
                     const int4 m = p[3];
-                    if (m.y < 0) continue;
-                    if (m.y >= g.n1) { atomicAdd(&st->bad_commit, 1); continue; }
-                    int4 v = p[0], d = p[1], c = p[2];
-                    d.x = resolve_dic(d.x, A.fifo, A.cap, head, A.poprank, (uint32_t)g.n); d.y = resolve_dic(d.y, A.fifo, A.cap, head, A.poprank, (uint32_t)g.n);
-                    d.z = resolve_dic(d.z, A.fifo, A.cap, head, A.poprank, (uint32_t)g.n); d.w = resolve_dic(d.w, A.fifo, A.cap, head, A.poprank, (uint32_t)g.n);
-                    int4 *o = reinterpret_cast<int4 *>(&A.mt[m.y]);
-                    // A slot that was hot before the batch, in a bucket without a pending decay, went through the bypass:
-                    // its score is written by the hot partition's workgroup (above) -- at any time, so the staged copy's
-                    // stale score must not be stored over it, not even as part of a wider store.
-                    bool k0 = false, k1 = false, k2 = false, k3 = false;
-                    if (g.hot && A.mt[m.y].flip == gflip) {
-                        const int4 told = o[1];
-                        k0 = told.x != 0; k1 = told.y != 0; k2 = told.z != 0; k3 = told.w != 0;
+                    on = on && m.y >= 0;
+                    if (on && m.y >= g.n1) { atomicAdd(&st->bad_commit, 1); on = false; }
+                    int4 d0 = make_int4(0, 0, 0, 0), d = d0;
+                    if (on) {
+                        const int4 v = p[0], c = p[2];
+                        d0 = p[1];
+                        d = d0;
+                        d.x = resolve_dic(d.x, A.fifo, A.cap, head, A.poprank, (uint32_t)g.n); d.y = resolve_dic(d.y, A.fifo, A.cap, head, A.poprank, (uint32_t)g.n);
+                        d.z = resolve_dic(d.z, A.fifo, A.cap, head, A.poprank, (uint32_t)g.n); d.w = resolve_dic(d.w, A.fifo, A.cap, head, A.poprank, (uint32_t)g.n);
+                        int4 *o = reinterpret_cast<int4 *>(&A.mt[m.y]);
+                        // A slot that was hot before the batch, in a bucket without a pending decay, went through the bypass:
+                        // its score is written by the hot partition's workgroup (above) -- at any time, so the staged copy's
+                        // stale score must not be stored over it, not even as part of a wider store.  The owner left the
+                        // mask of such slots in the staged bucket (cafe_core.h::hot_keep_mask): no look at the table here.
+                        const int keep = g.hot ? (m.z & 15) : 0;
+                        o[0] = v; o[1] = d;
+                        if (!keep) {
+                            o[2] = c;
+                        } else {
+                            int32_t *oc = reinterpret_cast<int32_t *>(&o[2]);
+                            if (!(keep & 1)) oc[0] = c.x;
+                            if (!(keep & 2)) oc[1] = c.y;
+                            if (!(keep & 4)) oc[2] = c.z;
+                            if (!(keep & 8)) oc[3] = c.w;
+                        }
+                        A.mt[m.y].flip = (uint32_t)m.x;
                     }
-                    o[0] = v; o[1] = d;
-                    if (!(k0 | k1 | k2 | k3)) {
-                        o[2] = c;
-                    } else {
-                        int32_t *oc = reinterpret_cast<int32_t *>(&o[2]);
-                        if (!k0) oc[0] = c.x;
-                        if (!k1) oc[1] = c.y;
-                        if (!k2) oc[2] = c.z;
-                        if (!k3) oc[3] = c.w;
-                    }
-                    A.mt[m.y].flip = (uint32_t)m.x;
+                    migrate_wave(d0.x, d.x); migrate_wave(d0.y, d.y); migrate_wave(d0.z, d.z); migrate_wave(d0.w, d.w);
                 }
             } else {
                 const LruBucket *stage = A.stage_l + offa;
@@ -2260,7 +2346,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     uint8_t *flags = w.flags.as<uint8_t>();
     int32_t *pushval = (int32_t *)(flags + (((size_t)n + 15) & ~(size_t)15));
     uint32_t *poprank = w.ranks.as<uint32_t>(), *pushrank = poprank + n, *clkrank = pushrank + n;
-    hipLaunchKernelGGL(k_finish, dim3(nb), dim3(kScanBlock), 0, st, g, tag, ctl, w.miss.as<uint8_t>(), w.outm.as<uint8_t>(),
+    hipLaunchKernelGGL(k_finish, dim3(nb), dim3(kThreads), 0, st, g, tag, ctl, w.miss.as<uint8_t>(), w.outm.as<uint8_t>(),
                        w.outl.as<uint8_t>(), w.evres.as<EvRes>(), d_ins, flags, pushval, w.agg.as<unsigned long long>(), poprank,
                        pushrank, clkrank, w.gotlist.as<uint32_t>(), sc, d_scores_out);
     CommitArgs CA;
@@ -2271,6 +2357,12 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     CA.mirror = reinterpret_cast<Mirror *>(s->d_pinned); CA.seq = s->call_seq;
     CA.reset_at = s->adjust ? s->lim * 1.2 : 1e300;
     CA.gotcount = w.ctl.as<uint32_t>() + kCtlWords + 2 * (size_t)kMaxParts + 4;
+    // migration inside the commit (cafe_backward_update_dev names the tables); only for calls the host verifies -- a
+    // batch walked in order by the closing workgroup has no staged placeholders to migrate from
+    const bool mig = s->mig.w_hot != nullptr && g.verify;
+    CA.w_hot = mig ? s->mig.w_hot : nullptr; CA.w_cold = s->mig.w_cold; CA.hash_size = s->mig.hash_size;
+    CA.local_ids = s->mig.local_ids; CA.batch = std::max(1, s->mig.batch); CA.dim = s->mig.dim; CA.hotn = std::max(1, s->mig.hotn);
+    s->mig_done = mig ? 1 : 0;
     const int cb = g.P1 + g.P2 + (g.hot ? g.PH : 0);
     // (the kernel's own completion signal is the event a plan made ahead for the NEXT call waits for: no marker packet)
     hipExtLaunchKernelGGL(k_commit, dim3(cb), dim3(256), 0, st, nullptr, s->ev_commit, 0, g, CA, sc);

@@ -106,6 +106,16 @@ struct cafe_sketch {
         hipStream_t st = nullptr;
     } hint;
     int64_t hint_used = 0, hint_cancelled = 0;
+    // tables of the step being issued (cafe_backward_update_dev): the insert's commit migrates the rows of the ids that
+    // take a slot itself (w_hot == nullptr: a bare sketch call, nothing to migrate); mig_done: the last insert did
+    struct Mig {
+        float *w_hot = nullptr;
+        float *const *w_cold = nullptr;
+        const int32_t *hash_size = nullptr;
+        const int64_t *local_ids = nullptr;
+        int batch = 0, dim = 0, hotn = 0;
+    } mig;
+    int mig_done = 0;
     hipEvent_t ev_fwd = nullptr;        // completion of the last cafe_forward_dev gather kernel
     const void *fwd_que = nullptr;      // ... and the routing array it wrote
     uint32_t last_moves = 0;            // moves (LRU -> main) of the newest call the host has a snapshot of
