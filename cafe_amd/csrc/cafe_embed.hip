@@ -1371,6 +1371,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
         bool simple = false;
         // the update in two kernels when there is a stream to run the first of them beside the insert
         const bool split = side != st && want_split_update(s, t, total);
+        s->split_active = split ? 1 : 0;
         if (split && s->opt_split_update != 2 && t->h_rows && (double)t->h_rows[0] > 0.4 * total) {
             t->split_pause = 256;            // (this step still runs split: the gather has queued its partition passes)
             t->h_rows[0] = 0;

@@ -108,6 +108,7 @@ struct ParWorkspace {
     DevBuf ctl;             // [Ctl][evcnt: 2*P1]
     DevBuf cm, colpref, tot, off, plan, items, ev, evres, miss, outm, outl, stage_m, stage_l, stage_tot, prevcnt;
     DevBuf hkey, hrun, hfin;
+    DevBuf items_sorted, pre_nmiss;      // k_presort: the partitions' records in owner order, misses per LRU partition
     DevBuf ldirty, myev, mycnt;
     DevBuf flags, agg, ranks, gotlist;
     void *evres_seen = nullptr;
@@ -604,6 +605,78 @@ __device__ inline void lsd_sort(SortTmp<CAP, MOVES> &t, int n, int bits, bool in
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------
+// plan, fourth kernel: the partitions in owner order
+// ------------------------------------------------------------------------------------------------
+// What a round-1 owner does before it needs a score -- bring its partition into bucket order (a stable sort: batch order
+// inside a bucket) -- depends on the ids and the pre-batch tables only, so it belongs to the plan, which runs beside the
+// forward or the previous step's last kernels, not to the chain that starts when the gradients arrive.  One workgroup per
+// round-1 owner sorts that owner's records exactly as the owner would (same keys, same lsd_sort) and writes them back in
+// that order; an LRU partition keeps its presumed misses only, and their number.  The owners of later rounds (k_fix) still
+// sort for themselves: their miss sets and move lists change from round to round.
+template <int CAP>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(CAP <= kCapSmall ? 6 : 1, 8)))
+k_presort(Geo g, Ctl *ctl, const uint32_t *__restrict__ off, const Rec *__restrict__ rec1, const Rec *__restrict__ rec2,
+          const Rec *__restrict__ rech, Rec *__restrict__ rec1s, Rec *__restrict__ rec2s, Rec *__restrict__ rechs,
+          uint32_t *__restrict__ pre_nmiss) {
+    CAFE_KWIN(7);
+    __shared__ __attribute__((aligned(16))) SortTmp<CAP, false> T;
+    __shared__ int s_miss;
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int nhot = (g.hot && !g.hot_table) ? g.PH : 0;
+    const Rec *recs;
+    Rec *out;
+    int total, bits, kind;           // kind 0 hot, 1 LRU, 2 main (class C)
+    if (b < nhot) {
+        const uint32_t o0 = off[off_hot0(g) + b];
+        total = (int)(off[off_hot0(g) + b + 1] - o0); recs = rech + o0; out = rechs + o0; bits = g.bitsh + 2; kind = 0;
+    } else if ((b -= nhot) < g.P2) {
+        const uint32_t o0 = off[off_lru0(g) + b];
+        total = (int)(off[off_lru0(g) + b + 1] - o0); recs = rec2 + o0; out = rec2s + o0; bits = g.bits2 + 1; kind = 1;
+    } else {
+        b -= g.P2;
+        const uint32_t o0 = off[2 * b];
+        total = (int)(off[2 * b + 1] - o0); recs = rec1 + o0; out = rec1s + o0; bits = g.bits1; kind = 2;
+    }
+    if (kind == 1 && tid == 0) { s_miss = 0; if (total == 0 || total > CAP) pre_nmiss[b] = 0; }
+    if (total == 0) return;
+    if (total > CAP) { if (tid == 0) ctl->overflow = 1; return; }       // the owner would refuse it too
+    constexpr int IPT = CAP / kThreads;
+    Rec rr[IPT];
+    const uint32_t dead = 1u << g.bits2;         // LRU: items that do not miss sort behind every bucket and are dropped
+    int mine = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int j = tid + k * kThreads;
+        if (j < total) {
+            rr[k] = recs[j];
+            uint32_t key = rr[k].bl;
+            if (kind == 1) { const bool ms = (key & kMissBit) != 0; key = ms ? (key & ~kMissBit) : dead; mine += ms; }
+            else if (kind == 2) key &= ~kMissBit;
+            T.grp[j] = key;
+        }
+    }
+    if (kind == 1) {
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+        if ((tid & 63) == 0 && mine) atomicAdd(&s_miss, mine);
+    }
+    __syncthreads();
+    const int keep = kind == 1 ? s_miss : total;
+    if (kind == 1 && tid == 0) pre_nmiss[b] = (uint32_t)keep;
+    if (keep == 0) return;
+    lsd_sort<CAP, false>(T, total, bits, false);
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int j = tid + k * kThreads;
+        if (j < total) {
+            const int s = T.lr[j];
+            if (s < keep) out[s] = rr[k];
+        }
+    }
+}
+
 // per-field sums of the norms from the partial sums into LDS (every workgroup gets the same floats: field_sum_tree);
 // a wave per field
 __device__ inline void field_sums(const Geo &g, const Score &sc, float *fsum) {
@@ -644,7 +717,8 @@ __device__ inline ScoreSrc score_src(const Geo &g, const Score &sc, const float 
 template <int CAP, bool MV>
 __device__ inline void hot_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy, float *fsum, const Geo &g, int p,
                                  const MainBucket *__restrict__ mt, const DevState *__restrict__ st, Ctl *ctl,
-                                 const uint32_t *__restrict__ off, const Rec *__restrict__ rech, const Score &sc,
+                                 const uint32_t *__restrict__ off, const Rec *__restrict__ rech, const Rec *__restrict__ rechs,
+                                 const Score &sc,
                                  unsigned long long *__restrict__ hkey, float *__restrict__ hrun, int2 *__restrict__ hfin,
                                  uint8_t *__restrict__ outm) {
     const int tid = threadIdx.x;
@@ -658,17 +732,36 @@ __device__ inline void hot_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy,
     const int b0 = p * g.bpph;
     const Rec *recs = rech + o0;
     if (total > 512) __builtin_amdgcn_s_setprio(3);
+    constexpr int IPT = CAP / kThreads;
+    const ScoreSrc ss = score_src(g, sc, fsum);
+    if (rechs) {
+        // the plan left the partition in owner order (k_presort): one coalesced read, no sort on this side of the scores
+        // (the first records are requested before the field sums are waited for)
+        constexpr int PRE = IPT < 8 ? IPT : 8;
+        Rec rr[PRE];
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) { const int s = tid + k * kThreads; if (s < total) rr[k] = rechs[o0 + s]; }
+        __syncthreads();                // field sums in place
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            const int s = tid + k * kThreads;
+            if (s < total) { L.s.sg[s] = rr[k].bl; L.s.stm[s] = 2u * rr[k].pos; L.s.pc[s] = ss.at(rr[k].pos); }
+        }
+        for (int s = tid + PRE * kThreads; s < total; s += kThreads) {
+            const Rec r = rechs[o0 + s];
+            L.s.sg[s] = r.bl; L.s.stm[s] = 2u * r.pos; L.s.pc[s] = ss.at(r.pos);
+        }
+        __syncthreads();
+    } else {
     for (int j = tid; j < total; j += kThreads) L.t.grp[j] = recs[j].bl;
     __syncthreads();
     CAFE_STAMP(g.prof, 1);
     lsd_sort<CAP, MV>(L.t, total, g.bitsh + 2, false);
     CAFE_STAMP(g.prof, 2);
-    constexpr int IPT = CAP / kThreads;
     uint16_t myr[IPT];
 #pragma unroll
     for (int k = 0; k < IPT; ++k) { const int j = tid + k * kThreads; myr[k] = j < total ? L.t.lr[j] : 0; }
     __syncthreads();
-    const ScoreSrc ss = score_src(g, sc, fsum);
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
         const int j = tid + k * kThreads;
@@ -679,6 +772,7 @@ __device__ inline void hot_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy,
         }
     }
     __syncthreads();
+    }
     CAFE_STAMP(g.prof, 3);
     const float thr = st->thr;
     int2 *fin = hfin + o0;
@@ -970,6 +1064,7 @@ struct MainCtx {
 };
 
 struct MainArgs {
+    const Rec *rec1s;           // round 1: the class C items of every partition in owner order (k_presort)
     const MainBucket *mt;
     const DevState *st;
     Ctl *ctl;
@@ -1041,6 +1136,26 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
     const Rec *recs = A.rec1 + o0;
     if (total > 512) __builtin_amdgcn_s_setprio(3);
 
+    constexpr int IPT = CAP / kThreads;
+    const ScoreSrc ss = score_src(g, sc, fsum);
+    bool presorted = false;
+    if constexpr (!MOVES) presorted = A.rec1s != nullptr;
+    if (presorted) {
+        // round 1: the class C items come in owner order from the plan (k_presort)
+        constexpr int PRE = IPT < 8 ? IPT : 8;
+        Rec rr[PRE];
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) { const int s = tid + k * kThreads; if (s < total) rr[k] = A.rec1s[o0 + s]; }
+        __syncthreads();                // field sums in place
+        auto put = [&](int s, const Rec &r) {
+            L.s.sg[s] = r.bl & ~kMissBit; L.s.stm[s] = 2u * r.pos; L.s.px[s] = r.x; L.s.pc[s] = ss.at(r.pos);
+            L.s.po[s] = (uint8_t)((r.bl & kMissBit) ? 1 : 0);
+        };
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) { const int s = tid + k * kThreads; if (s < total) put(s, rr[k]); }
+        for (int s = tid + PRE * kThreads; s < total; s += kThreads) put(s, A.rec1s[o0 + s]);
+        __syncthreads();
+    } else {
     // elements: [0, nc) class C items, [nc, np) class M items, [np, total) moves
     for (int j = tid; j < total; j += kThreads) {
         if (j < np) {
@@ -1080,12 +1195,10 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
     CAFE_STAMP(g.prof, 1);
     lsd_sort<CAP, MV>(L.t, total, g.bits1, MOVES);
     CAFE_STAMP(g.prof, 2);
-    constexpr int IPT = CAP / kThreads;
     uint16_t myr[IPT];
 #pragma unroll
     for (int k = 0; k < IPT; ++k) { const int j = tid + k * kThreads; myr[k] = j < total ? L.t.lr[j] : 0; }
     __syncthreads();
-    const ScoreSrc ss = score_src(g, sc, fsum);
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
         const int j = tid + k * kThreads;
@@ -1107,6 +1220,7 @@ __device__ inline void main_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy
         }
     }
     __syncthreads();
+    }
 
     CAFE_STAMP(g.prof, 3);
     const float thr = A.st->thr;
@@ -1323,6 +1437,8 @@ struct LruCtx {
 };
 
 struct LruArgs {
+    const Rec *rec2s;           // round 1: the presumed misses of every partition in owner order (k_presort)
+    const uint32_t *pre_nmiss;  // ... and how many there are
     const LruBucket *lt;
     const DevState *st;
     Ctl *ctl;
@@ -1370,6 +1486,25 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
     field_sums(g, sc, fsum);
     const int b0 = q * g.bpp2;
     const Rec *recs = A.rec2 + o0;
+    constexpr int IPT = CAP / kThreads;
+    const ScoreSrc ss = score_src(g, sc, fsum);
+    int nmiss;
+    if (round == 1 && A.rec2s) {
+        // round 1: the presumed misses come in owner order from the plan (k_presort), with their number
+        nmiss = (int)A.pre_nmiss[q];
+        if (tid == 0) { A.stage_tot[g.P1 + q] = (uint32_t)nmiss; if (nmiss == 0) A.mycnt[q] = 0; }
+        if (nmiss == 0) return;
+        constexpr int PRE = IPT < 8 ? IPT : 8;
+        Rec rr[PRE];
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) { const int s = tid + k * kThreads; if (s < nmiss) rr[k] = A.rec2s[o0 + s]; }
+        __syncthreads();                // field sums in place
+        auto put = [&](int s, const Rec &r) { L.s.sg[s] = r.bl & ~kMissBit; L.s.stm[s] = r.pos; L.s.px[s] = r.x; L.s.pc[s] = ss.at(r.pos); };
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) { const int s = tid + k * kThreads; if (s < nmiss) put(s, rr[k]); }
+        for (int s = tid + PRE * kThreads; s < nmiss; s += kThreads) put(s, A.rec2s[o0 + s]);
+        __syncthreads();
+    } else {
     // items that did not miss get a key behind every bucket: they sort to the end and are dropped
     const uint32_t dead = 1u << g.bits2;
     int mine = 0;
@@ -1385,18 +1520,16 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
     if ((tid & 63) == 0 && mine) atomicAdd(s_total, mine);
     __syncthreads();
-    const int nmiss = *s_total;
+    nmiss = *s_total;
     if (tid == 0) { A.stage_tot[g.P1 + q] = (uint32_t)nmiss; if (nmiss == 0) A.mycnt[q] = 0; }
     if (nmiss == 0) return;
     CAFE_STAMP(g.prof, 1);
     lsd_sort<CAP, MV>(L.t, cnt, g.bits2 + 1, false);
     CAFE_STAMP(g.prof, 2);
-    constexpr int IPT = CAP / kThreads;
     uint16_t myr[IPT];
 #pragma unroll
     for (int k = 0; k < IPT; ++k) { const int j = tid + k * kThreads; myr[k] = j < cnt ? L.t.lr[j] : 0; }
     __syncthreads();
-    const ScoreSrc ss = score_src(g, sc, fsum);
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
         const int j = tid + k * kThreads;
@@ -1407,6 +1540,7 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
         }
     }
     __syncthreads();
+    }
 
     CAFE_STAMP(g.prof, 3);
     const float thr = A.st->thr;
@@ -1543,6 +1677,7 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
 // round 1: hot partitions, LRU partitions and main partitions (class C) in one launch
 // ------------------------------------------------------------------------------------------------
 struct HotArgs {
+    const Rec *rechs;           // the hot list's partitions in owner order (k_presort)
     const Rec *rech;
     unsigned long long *hkey;
     float *hrun;
@@ -1575,7 +1710,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(C
                 hot_table_owner(tab + wave * (kHotKeys + 64), tab + wave * (kHotKeys + 64) + kHotKeys, fsum, g, ph, MA.mt, MA.st, MA.off,
                                 HA.rech, sc, HA.hkey, HA.hrun, HA.hfin, MA.outm);
         } else {
-            hot_owner<CAP, false>(L, heavy, &n_heavy, fsum, g, b, MA.mt, MA.st, MA.ctl, MA.off, HA.rech, sc, HA.hkey, HA.hrun, HA.hfin, MA.outm);
+            hot_owner<CAP, false>(L, heavy, &n_heavy, fsum, g, b, MA.mt, MA.st, MA.ctl, MA.off, HA.rech, HA.rechs, sc, HA.hkey, HA.hrun, HA.hfin, MA.outm);
         }
         CAFE_STAMP(0, 6);
         return;
@@ -2170,7 +2305,7 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     const size_t mat = (size_t)g.nchunks * g.nbins;
     if (w.ctl.reserve(4 * (kCtlWords + 2 * (size_t)kMaxParts + 16)) || w.cm.reserve(2 * mat + 16) || w.colpref.reserve(4 * mat + 16) ||
         w.tot.reserve(4 * (size_t)g.nbins + 16) || w.off.reserve(4 * ((size_t)g.nbins + 8)) || w.plan.reserve(8 * N + 16) ||
-        w.items.reserve(3 * sizeof(Rec) * N + 64) || w.hkey.reserve(8 * N + 16) || w.hrun.reserve(4 * N + 16) || w.hfin.reserve(8 * N + 16) ||
+        w.items.reserve(3 * sizeof(Rec) * N + 64) || w.items_sorted.reserve(3 * sizeof(Rec) * N + 64) || w.pre_nmiss.reserve(4 * (size_t)kMaxParts + 16) || w.hkey.reserve(8 * N + 16) || w.hrun.reserve(4 * N + 16) || w.hfin.reserve(8 * N + 16) ||
         w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * g.evs) || w.evres.reserve(sizeof(EvRes) * N + 64) || w.miss.reserve(N + 16) ||
         w.outm.reserve(N + 16) || w.outl.reserve(N + 16) ||
         w.stage_m.reserve(sizeof(MainBucket) * (N + (size_t)g.P1 * g.evs)) || w.stage_l.reserve(sizeof(LruBucket) * N + 128) ||
@@ -2234,6 +2369,7 @@ static int pick_cap(cafe_sketch *s, int n) {
 // The plan of an insert of n ids: classification, partition offsets, item records; per-call scalars and a zeroed
 // control block.  Reads the ids and the pre-batch tables only.
 // `done`: an event completed by the last plan kernel itself (its completion signal; no marker packet behind it)
+static int pick_cap(cafe_sketch *s, int n);
 static int launch_plan(cafe_sketch *s, Geo &g, const IdSrc &ids, hipStream_t pre, hipEvent_t done = nullptr) {
     ParWorkspace &w = *s->par;
     const int n = g.n;
@@ -2251,9 +2387,30 @@ static int launch_plan(cafe_sketch *s, Geo &g, const IdSrc &ids, hipStream_t pre
     hipLaunchKernelGGL(k_assign, dim3(g.nchunks), dim3(kPlanThreads), plan_lds, pre, g, s->d_main, ids, w.cm.as<uint16_t>(), planA, planB);
     hipLaunchKernelGGL(k_offsets, dim3((g.nbins + kOffBins - 1) / kOffBins), dim3(kThreads), 0, pre, g, w.cm.as<uint16_t>(),
                        w.colpref.as<uint32_t>(), w.tot.as<uint32_t>(), off, ctl, evcnt, s->d_state);
-    hipExtLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, pre, nullptr, done, 0, g, ids, (const uint32_t *)planA,
-                          (const uint32_t *)planB, (const uint32_t *)w.colpref.as<uint32_t>(), (const uint32_t *)off, rec1, rec2, rech,
-                          w.miss.as<uint8_t>());
+    // (the plan's completion event rides on its last kernel: no marker packet)
+    // The owner-order pass pays where the insert's chain is the step's critical path.  Where the update runs split (its
+    // gradient pass sits beside the chain and the row updates wait for IT), a shorter chain buys nothing and one more
+    // kernel beside the gather costs: measured on MI355X, cfg2 (D = 16) -5.5 % step time with the pass, cfg3 (D = 128,
+    // split update) +2 %.  The caller of the fused step tells which it is (split_active).
+    const bool presort = s->opt_presort && !s->split_active;
+    s->plan_presort = presort ? 1 : 0;
+    hipExtLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, pre, nullptr, presort ? nullptr : done, 0, g, ids,
+                          (const uint32_t *)planA, (const uint32_t *)planB, (const uint32_t *)w.colpref.as<uint32_t>(),
+                          (const uint32_t *)off, rec1, rec2, rech, w.miss.as<uint8_t>());
+    if (!presort) { CAFE_HIP_CHECK(hipGetLastError()); return 0; }     // the owners sort for themselves
+    // the partitions in owner order (the owners of this capacity; a partition that does not fit flags the batch, which is
+    // then issued again with the largest owners like any other workspace limit)
+    Rec *rec1s = w.items_sorted.as<Rec>(), *rec2s = rec1s + n, *rechs = rec2s + n;
+    const int grid1 = ((g.hot && !g.hot_table) ? g.PH : 0) + g.P2 + g.P1;
+    const int cap = pick_cap(s, n);
+
+#define CAFE_PRESORT(C)                                                                                                         \
+    hipExtLaunchKernelGGL((k_presort<C>), dim3(grid1), dim3(kThreads), 0, pre, nullptr, done, 0, g, ctl, (const uint32_t *)off,     \
+                          (const Rec *)rec1, (const Rec *)rec2, (const Rec *)rech, rec1s, rec2s, rechs, w.pre_nmiss.as<uint32_t>())
+    if (cap == kCapSmall) CAFE_PRESORT(kCapSmall);
+    else if (cap == 2048) CAFE_PRESORT(2048);
+    else CAFE_PRESORT(8192);
+#undef CAFE_PRESORT
     CAFE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -2321,6 +2478,10 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     LA.stage_tot = w.stage_tot.as<uint32_t>(); LA.ldirty = w.ldirty.as<uint8_t>(); LA.myev = w.myev.as<MoveEv>();
     LA.mycnt = w.mycnt.as<uint32_t>();
     HotArgs HA;
+    const bool sorted = s->plan_presort != 0;          // as the plan in hand was made (launch_plan)
+    HA.rechs = (g.hot_table || !sorted) ? nullptr : (const Rec *)(w.items_sorted.as<Rec>() + 2 * (size_t)n);
+    MA.rec1s = sorted ? w.items_sorted.as<Rec>() : nullptr; LA.rec2s = sorted ? w.items_sorted.as<Rec>() + n : nullptr;
+    LA.pre_nmiss = w.pre_nmiss.as<uint32_t>();
     HA.rech = rech; HA.hkey = w.hkey.as<unsigned long long>(); HA.hrun = w.hrun.as<float>(); HA.hfin = w.hfin.as<int2>();
     const int cap = pick_cap(s, n);
     if (s->ev_chain[0]) (void)hipEventRecord(s->ev_chain[0], st);
@@ -2377,7 +2538,7 @@ void par_free(cafe_sketch *s) {
     ParWorkspace &w = *s->par;
     DevBuf *all[] = {&w.ctl, &w.cm, &w.colpref, &w.tot, &w.off, &w.plan, &w.items, &w.ev, &w.evres, &w.miss, &w.outm, &w.outl,
                      &w.stage_m, &w.stage_l, &w.stage_tot, &w.prevcnt, &w.ldirty, &w.myev, &w.mycnt, &w.flags, &w.agg, &w.ranks,
-                     &w.gotlist, &w.hkey, &w.hrun, &w.hfin};
+                     &w.gotlist, &w.hkey, &w.hrun, &w.hfin, &w.items_sorted, &w.pre_nmiss};
     for (DevBuf *b : all) b->release();
     delete s->par;
     s->par = nullptr;

@@ -81,6 +81,8 @@ struct cafe_sketch {
     uint32_t plan_seq = 0;
     const void *plan_ids = nullptr, *plan_expect = nullptr;   // plan_expect: the ids of the insert being issued
     int opt_plan_ahead = 1, unused_plans = 0;
+    int opt_presort = 1, plan_presort = 0;     // the plan leaves the partitions in owner order (k_presort); as the last plan was made
+    int split_active = 0;                      // the fused step's update runs split (cafe_backward_update_dev): see launch_plan
     double host_us[4] = {0, 0, 0, 0};   // diagnostics (cafe_debug_host_times)
     long long counters_plan_ahead = 0;
     long long last_seen_batch = -1;

@@ -100,7 +100,8 @@ int cafe_sketch_rebuild_free_list(cafe_sketch_t *s, cafe_stream_t stream);
  * "split_update" (0 / 1 / 2 = cafe_backward_update_dev updates the tables with one kernel / with two by the library's
  * rule / always with two: segment sums on a third stream beside the sketch insert, row updates behind the migration), "overlap" (bit 0: the plan of an insert,
  * bit 1: the update's partition passes run on the handle's second stream; 0 = one stream), "fuse_fields" (0 =
- * cafe_backward_update_dev with per_field always issues field by field), "verify", "move_cap" (moves one main
+ * cafe_backward_update_dev with per_field always issues field by field), "verify", "presort" (0 = the plan of an insert does not leave the partitions in owner order: the round-1 owners sort for
+ * themselves), "move_cap" (moves one main
  * partition accepts per round, at most 512: a test aid), "exact_reset" (accepted and ignored: the reset decision is
  * always made on the exact real_n, on the device). */
 int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int value);

@@ -25,7 +25,7 @@ import os
 if os.environ.get("CAFE_IDS_READY"):
     eng.sketch.set_option("ids_ready", 1)
 names = {"embed": ["k_forward", "k_grad_norm", "k_migrate_list", "k_bwd_assign", "k_bwd_offsets", "k_bwd_scatter", "k_bwd_segments", "k_bwd_apply"],
-         "insert": ["k_assign", "k_offsets", "k_scatter", "k_round1", "k_fix", "k_finish", "k_commit"]}
+         "insert": ["k_assign", "k_offsets", "k_scatter", "k_round1", "k_fix", "k_finish", "k_commit", "k_presort"]}
 
 
 def read():
