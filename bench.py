@@ -270,16 +270,19 @@ def main():
     if world == 1:
         L.cafe_tables_set_timing(coll.tables, 1)
         acc = [0.0, 0.0, 0.0, 0.0, 0.0]
+        cnt = [0, 0, 0, 0, 0]
         kreps = 20
         ms = ctypes.c_float()
         for _ in range(kreps):
             step(it); it += 1
             for k in range(5):
-                if L.cafe_tables_kernel_ms(coll.tables, k, ctypes.byref(ms)) == 0:      # [4] only exists for split updates
-                    acc[k] += ms.value
+                # a timer the last step did not record is refused ([4] only exists for split updates): each average is over
+                # the steps that really ran that kernel
+                if L.cafe_tables_kernel_ms(coll.tables, k, ctypes.byref(ms)) == 0:
+                    acc[k] += ms.value; cnt[k] += 1
         L.cafe_tables_set_timing(coll.tables, 0)
-        kern = [a / kreps for a in acc]
-        split_update = kern[4] > 0
+        kern = [a / max(c, 1) for a, c in zip(acc, cnt)]
+        split_update = cnt[4] > kreps // 2
         update_parts = {"k_bwd_segments_us": round(kern[1] * 1e3, 2), "k_bwd_apply_us": round(kern[4] * 1e3, 2)}
         kern[1] += kern[4]
     per_gpu = None

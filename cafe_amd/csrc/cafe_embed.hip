@@ -87,6 +87,12 @@ extern "C" int cafe_tables_set_timing(cafe_tables_t *t, int on) {
 
 extern "C" int cafe_tables_kernel_ms(cafe_tables_t *t, int which, float *ms) {
     if (which < 0 || which > 4 || !t->ev_t[which][0]) { set_error("cafe_tables_kernel_ms: timing was not enabled"); return 1; }
+    // a pair that the LAST step did not record (the second kernel of the update when it ran as one kernel; the other form
+    // after the rule switched) would return an older step's time
+    if (t->ev_epoch[which] != (which == 0 ? t->fwd_epoch : t->bwd_epoch)) {
+        set_error("cafe_tables_kernel_ms: timer %d was not recorded by the last step", which);
+        return 1;
+    }
     CAFE_HIP_CHECK(hipEventSynchronize(t->ev_t[which][1]));
     const hipError_t e = hipEventElapsedTime(ms, t->ev_t[which][0], t->ev_t[which][1]);
     if (e != hipSuccess) {
@@ -113,6 +119,7 @@ extern "C" int cafe_tables_destroy(cafe_tables_t *t) {
             if (t->ev_t[k][j]) (void)hipEventDestroy(t->ev_t[k][j]);
     if (t->ev_plan) (void)hipEventDestroy(t->ev_plan);
     if (t->ev_sums) (void)hipEventDestroy(t->ev_sums);
+    if (t->ev_rows) (void)hipEventDestroy(t->ev_rows);
     if (t->h_rows) (void)hipHostFree(t->h_rows);
     t->ws_bwd_e.release(); t->ws_bwd_f.release();
     (void)hipFree(t->d_w_cold); (void)hipFree(t->d_id_offset); (void)hipFree(t->d_hash_size); (void)hipFree(t->d_cold_base);
@@ -261,6 +268,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     // reads) runs beside the gather on the sketch's second stream, behind everything queued on `st` so far.  Stopped
     // when forwards come without updates (inference), resumed by the next cafe_backward_update_dev.
     bool plan = false, plan_launched = false;
+    if (total >= 32768 && s->opt_overlap && cafe::ensure_streams(s)) return 1;
     if (d_local_ids && s->opt_plan_ahead && s->opt_overlap && !s->opt_serial && s->opt_fuse_fields && s->side_stream &&
         s->side_stream != st && total >= 32768 && total <= cafe::kParMaxIds && t->num_fields <= kMaxSeg) {
         if (s->plan_valid) s->unused_plans++;
@@ -301,7 +309,8 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
                           (const MainBucket *)s->d_main, fm1, (const float *)t->d_w_hot, (float *const *)t->d_w_cold, \
                           (const int64_t *)t->d_id_offset, (const int32_t *)t->d_hash_size, d_local_ids, d_in_gids, d_fields, batch, total, \
                           t->dim, t->hotn, d_gids, d_que, d_out, (const float *)nullptr, 1, (const DevState *)nullptr, 0, (int32_t *)nullptr)
-    if (t->timing) (void)hipEventRecord(t->ev_t[0][0], st);
+    t->fwd_epoch++;
+    if (t->timing) { (void)hipEventRecord(t->ev_t[0][0], st); t->ev_epoch[0] = t->fwd_epoch; }
     switch (lpg) {
         case 1: CAFE_FWD(1); break;
         case 2: CAFE_FWD(2); break;
@@ -1207,6 +1216,11 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     uint4 *entries = ecount ? reinterpret_cast<uint4 *>(ecount + 16) : nullptr, *elist = entries ? entries + total : nullptr;
     float4 *sums = t->ws_bwd_f.p ? t->ws_bwd_f.as<float4>() : nullptr;
     if (part & 1) {
+        // The partition workspaces are one set per tables handle.  Passes queued earlier on another stream (a forward's, on
+        // the third stream) may still be running: these wait for them; and whatever partition an earlier forward left is
+        // gone (cafe_forward_dev names its own again after this call).
+        if (t->ev_plan && t->plan_stream && t->plan_stream != pst) CAFE_HIP_CHECK(hipStreamWaitEvent(pst, t->ev_plan, 0));
+        t->bwd_plan_que = nullptr;
         hipLaunchKernelGGL(k_bwd_assign, dim3((total + kBwdChunk - 1) / kBwdChunk), dim3(1024), 4 * (size_t)P, pst, Ph, Pc, d_fields,
                            d_que, t->d_hash_size, t->d_cold_base, t->hotn, batch, total, cnt, rank, keys);
         hipLaunchKernelGGL(k_bwd_offsets, dim3(1), dim3(1024), 0, pst, Ph, P, cnt, off, tiles, ecount);
@@ -1215,6 +1229,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         if (pst != st || (part & 4)) {
             if (!t->ev_plan) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_plan, kDeviceEvent));
             CAFE_HIP_CHECK(hipEventRecord(t->ev_plan, pst));
+            t->plan_stream = pst;
         }
     }
     if (!(part & 14)) { CAFE_HIP_CHECK(hipGetLastError()); return 0; }
@@ -1246,21 +1261,28 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     }
     if (part & 2) {
         if (pst != st) CAFE_HIP_CHECK(hipStreamWaitEvent(st, t->ev_plan, 0));
-        if (t->timing) (void)hipEventRecord(t->ev_t[1][0], st);
+        if (t->timing) { (void)hipEventRecord(t->ev_t[1][0], st); t->ev_epoch[1] = t->bwd_epoch; }
         CAFE_SEG_ALL(false)
         if (t->timing) (void)hipEventRecord(t->ev_t[1][1], st);
     }
     if (part & 4) {
         if (pst != st) CAFE_HIP_CHECK(hipStreamWaitEvent(st, t->ev_plan, 0));
-        if (t->timing) (void)hipEventRecord(t->ev_t[1][0], st);
+        if (t->timing) { (void)hipEventRecord(t->ev_t[1][0], st); t->ev_epoch[1] = t->bwd_epoch; }
         CAFE_SEG_ALL(true)
         if (t->timing) (void)hipEventRecord(t->ev_t[1][1], st);          // the gradient pass alone (as a profiler reports it)
-        hipLaunchKernelGGL(k_bwd_compact, dim3((total + 1023) / 1024), dim3(256), 0, st, total, entries, ecount, elist, d_fields, t->d_w_hot,
-                           t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim);
+        // (the list's completion event rides on the kernel itself: no marker packet between it and the waiting stream)
         if (!t->ev_sums) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_sums, kDeviceEvent));
-        CAFE_HIP_CHECK(hipEventRecord(t->ev_sums, st));
+        hipExtLaunchKernelGGL(k_bwd_compact, dim3((total + 1023) / 1024), dim3(256), 0, st, nullptr, t->ev_sums, 0, total, (const uint4 *)entries,
+                              ecount, elist, d_fields, t->d_w_hot, t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim);
+        // the row count for the host's rule: copied to pinned memory behind the list kernel, read by a later step once the
+        // event behind the copy reports it landed (never waited for; no new copy while one is in flight)
         if (!t->h_rows) { CAFE_HIP_CHECK(hipHostMalloc((void **)&t->h_rows, 64, hipHostMallocDefault)); t->h_rows[0] = 0; }
-        CAFE_HIP_CHECK(hipMemcpyAsync(t->h_rows, ecount, 4, hipMemcpyDeviceToHost, st));      // read by a later step, never waited for
+        if (!t->ev_rows) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_rows, hipEventDisableTiming));
+        if (!t->rows_pending) {
+            CAFE_HIP_CHECK(hipMemcpyAsync(t->h_rows, ecount, 4, hipMemcpyDeviceToHost, st));
+            CAFE_HIP_CHECK(hipEventRecord(t->ev_rows, st));
+            t->rows_pending = 1;
+        }
     }
 #undef CAFE_SEG_ALL
 #undef CAFE_SEG
@@ -1269,7 +1291,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         // a lane group per row; the rows of a step are at most its lookups, usually a fraction of them
         const int G = 256 / lpg;
         const int agrid = std::max(1, std::min((total + G - 1) / G, 4096));
-        if (t->timing) (void)hipEventRecord(t->ev_t[4][0], st);
+        if (t->timing) { (void)hipEventRecord(t->ev_t[4][0], st); t->ev_epoch[4] = t->bwd_epoch; }
 #define CAFE_APPLY(L, V)                                                                                                 \
     hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, t->dim, lr, skip_rej, skip_seq)
         if (vpl == 1) {
@@ -1352,6 +1374,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
         if (cadence && !cafe::threshold_known_above_one(s)) fuse = false;
     }
     const double t_begin = now_us();
+    t->bwd_epoch++;
     if (fuse) {
         // What does not depend on this step's gradients runs on the sketch's second stream, beside the norm kernel: the
         // plan of the insert (ids and pre-batch tables only) and the partition passes of the backward (routing of the
@@ -1359,6 +1382,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
         // this step's forward) is ordered before them.  (Small steps are launch-bound: the cross-stream dependencies
         // cost more than the overlap returns.)
         hipStream_t side = st;
+        if (s->opt_overlap && total >= 32768 && cafe::ensure_streams(s)) return 1;
         if (s->opt_overlap && s->side_stream && s->side_stream != st && total >= 32768) side = s->side_stream;
         const size_t norm_floats = (size_t)total + (size_t)F * kMaxNormParts;
         if (t->ws_norm.reserve(norm_floats * 4 + 16) || cafe::par_prepare(s, total)) return 1;
@@ -1372,9 +1396,10 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
         // the update in two kernels when there is a stream to run the first of them beside the insert
         const bool split = side != st && want_split_update(s, t, total);
         s->split_active = split ? 1 : 0;
-        if (split && s->opt_split_update != 2 && t->h_rows && (double)t->h_rows[0] > 0.4 * total) {
+        uint32_t rows_seen = 0;
+        if (t->rows_pending && hipEventQuery(t->ev_rows) == hipSuccess) { rows_seen = t->h_rows[0]; t->rows_pending = 0; }
+        if (split && s->opt_split_update != 2 && (double)rows_seen > 0.4 * total) {
             t->split_pause = 256;            // (this step still runs split: the gather has queued its partition passes)
-            t->h_rows[0] = 0;
         } else if (!split && t->split_pause > 0) {
             t->split_pause--;
         }
@@ -1394,7 +1419,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             const bool early = split && attempt == 0 && s->fwd_que == d_que && t->bwd_plan_que == d_que && t->bwd_plan_fwd == s->fwd_count;
             if (early) plan_done = true;
             if (attempt == 0) {
-                if (t->timing) (void)hipEventRecord(t->ev_t[3][0], st);
+                if (t->timing) { (void)hipEventRecord(t->ev_t[3][0], st); t->ev_epoch[3] = t->bwd_epoch; }
                 if (norms_common(t, d_grad_out, batch, gn, psum, &nparts, st, split ? s->ev_gn : nullptr)) return 1;
                 if (t->timing) (void)hipEventRecord(t->ev_t[3][1], st);
                 if (early) {
@@ -1412,7 +1437,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             s->verify_mode = 1;
             s->plan_expect = d_local_ids;
             s->unused_plans = 0;
-            if (t->timing) s->ev_chain[0] = t->ev_t[2][0], s->ev_chain[1] = t->ev_t[2][1];
+            if (t->timing) { s->ev_chain[0] = t->ev_t[2][0], s->ev_chain[1] = t->ev_t[2][1]; t->ev_epoch[2] = t->bwd_epoch; }
             // the insert's commit copies the rows of the ids that take a slot itself (sk_embedding_bag.py:199-208)
             s->mig.w_hot = t->d_w_hot; s->mig.w_cold = t->d_w_cold; s->mig.hash_size = t->d_hash_size; s->mig.local_ids = d_local_ids;
             s->mig.batch = batch; s->mig.dim = t->dim; s->mig.hotn = t->hotn;
@@ -1450,7 +1475,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             bool spec = false;
             cafe_sketch::Hint &h = s->hint;
             if (attempt == 0 && h.valid && !h.enqueued && h.t == t && h.st == st && h.batch == batch && h.que != d_que &&
-                h.gids != d_gids && s->side_stream) {
+                h.gids != d_gids) {
                 if (forward_common(s, t, h.ids, nullptr, nullptr, batch, (long)total, h.gids, h.que, h.out, st, true)) return 1;
                 h.enqueued = 1;
                 spec = true;
@@ -1496,8 +1521,10 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
                 s->plan_valid = 0;
                 s->fwd_que = nullptr;
                 t->bwd_plan_que = nullptr;
-                CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, s->side_stream));
-                CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));
+                if (s->side_stream) {
+                    CAFE_HIP_CHECK(hipEventRecord(s->ev_head_join, s->side_stream));
+                    CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_join, 0));
+                }
                 if (s->low_stream) {
                     CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, s->low_stream));
                     CAFE_HIP_CHECK(hipStreamWaitEvent(st, s->ev_head_fork, 0));

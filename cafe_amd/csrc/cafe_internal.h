@@ -150,6 +150,10 @@ struct cafe_tables {
     // [4] the hot-table half of k_bwd_segments when it runs on the second stream
     hipEvent_t ev_t[5][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     hipEvent_t ev_plan = nullptr;    // partition passes of the backward done (recorded on the sketch's side stream)
+    hipStream_t plan_stream = nullptr;  // ... the stream it was last recorded on
+    hipEvent_t ev_rows = nullptr;    // the copy of the split update's row count to pinned memory has landed
+    int rows_pending = 0;
+    uint64_t fwd_epoch = 0, bwd_epoch = 0, ev_epoch[5] = {0, 0, 0, 0, 0};     // which step recorded each timer pair
     const void *bwd_plan_que = nullptr; // routing array the partition passes queued by the last gather read
     uint64_t bwd_plan_fwd = 0;
     // rows / lookups of the last split update that has reported (k_bwd_compact's count, copied to pinned memory): a step
@@ -175,6 +179,7 @@ void par_free(cafe_sketch *s);
 const uint32_t *par_gotcount(cafe_sketch *s);
 const uint32_t *par_gotlist(cafe_sketch *s);
 // cafe_sketch.hip
+int ensure_streams(cafe_sketch *s);          // creates the handle's second and third stream on first use
 int launch_serial_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_scores, int n, int32_t *d_ins, hipStream_t st);
 long long real_n_bound(cafe_sketch *s);
 bool threshold_known_above_one(cafe_sketch *s);

@@ -349,6 +349,25 @@ static int run_reset(cafe_sketch *s, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------------
+// The handle's own streams, created by the first step that is large enough to use them (>= 32768 lookups): a sketch
+// that only ever sees small calls holds no hardware queues (a process with dozens of handles would otherwise keep far
+// more queues than the hardware schedules at once).
+int cafe::ensure_streams(cafe_sketch *s) {
+    if (s->side_stream) return 0;
+    // the second stream carries the short plan kernels beside the bandwidth kernels: highest priority, so that their
+    // workgroups are placed as soon as compute-unit slots free up
+    int prio_least = 0, prio_most = 0;
+    CAFE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_most));
+    CAFE_HIP_CHECK(hipStreamCreateWithPriority(&s->side_stream, hipStreamNonBlocking, prio_most));
+    // The third one carries a bandwidth kernel beside the insert's short kernels.  Default priority, not the lowest: the
+    // caller's stream waits for this one (the row updates wait for the segment sums), and in a process that holds more
+    // queues than the hardware schedules at once a lowest-priority queue was never scheduled while the waiting queue
+    // counted as busy (a full test session hung at the first step of its 29th test).
+    (void)prio_least;
+    CAFE_HIP_CHECK(hipStreamCreateWithPriority(&s->low_stream, hipStreamNonBlocking, 0));
+    return 0;
+}
+
 extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, int adjust_thres, double alpha,
                                   int lru_first) {
     if (!out || lim < 10) { set_error("cafe_sketch_create: lim must be >= 10 (got %d)", lim); return 1; }
@@ -370,19 +389,6 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     CAFE_HIP_CHECK(hipHostMalloc((void **)&s->h_pinned, 256, hipHostMallocMapped));
     memset(s->h_pinned, 0, 256);
     CAFE_HIP_CHECK(hipHostGetDevicePointer((void **)&s->d_pinned, s->h_pinned, 0));
-    {
-        // the second stream carries the short plan kernels beside the bandwidth kernels: highest priority, so that
-        // their workgroups are placed as soon as compute-unit slots free up
-        int prio_least = 0, prio_most = 0;
-        CAFE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_most));
-        CAFE_HIP_CHECK(hipStreamCreateWithPriority(&s->side_stream, hipStreamNonBlocking, prio_most));
-        // The third one carries a bandwidth kernel beside the insert's short kernels.  Default priority, not the lowest:
-        // the caller's stream waits for this one (the row updates wait for the segment sums), and in a process that
-        // holds more queues than the hardware schedules at once a lowest-priority queue was never scheduled while the
-        // waiting queue counted as busy (a full test session hung at the first step of its 29th test).
-        (void)prio_least;
-        CAFE_HIP_CHECK(hipStreamCreateWithPriority(&s->low_stream, hipStreamNonBlocking, 0));
-    }
     if (const char *e = getenv("CAFE_OVERLAP")) s->opt_overlap = atoi(e);
     if (const char *e = getenv("CAFE_SPLIT_UPDATE")) s->opt_split_update = atoi(e);
     CAFE_HIP_CHECK(hipEventCreateWithFlags(&s->ev_head_fork, kDeviceEvent));
@@ -785,8 +791,13 @@ static int wait_last(cafe_sketch *s, Mirror *m) {
                         "events: plan %s, forward %s, norms %s\n", s->call_seq, *seqp, name(q),
                         s->side_stream ? name(hipStreamQuery(s->side_stream)) : "-", s->low_stream ? name(hipStreamQuery(s->low_stream)) : "-",
                         name(hipEventQuery(s->ev_plan)), name(hipEventQuery(s->ev_fwd)), s->ev_gn ? name(hipEventQuery(s->ev_gn)) : "-");
-                CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));
-                break;
+                // a library call must not block for ever: the call fails (CAFE_WAIT_FOREVER=1: keep waiting, for debugging)
+                if (const char *e = getenv("CAFE_WAIT_FOREVER"); e && atoi(e)) {
+                    CAFE_HIP_CHECK(hipStreamSynchronize(s->last_stream));
+                    break;
+                }
+                set_error("call %u: no verdict from the device after 10 s (snapshot %u); the streams' states are on stderr", s->call_seq, *seqp);
+                return 1;
             }
             __builtin_ia32_pause();
         }

@@ -308,3 +308,34 @@ def test_fused_steps_that_the_device_rejects_stay_exact(option, value, reason, h
         assert dropped > 0, (used, dropped)      # forwards queued ahead were dropped behind rejected steps
     assert c["left_parallel_path"][reason] > 0, c
     assert c["cadence_miss"] == 0
+
+
+def test_many_live_handles_do_not_starve_a_split_update_step(oracle_mod):
+    """a process that holds dozens of sketch handles must not end up with more hardware queues than
+    the device schedules (round 2: a step of the 29th test of a session never finished).  Handles create their own
+    streams only when a step is large enough to use them: 40 live handles that only ever see small calls hold none, and
+    a split-update step (which uses all three streams) on another handle completes and matches the oracle."""
+    from cafe_amd.collection import CafeEmbeddingCollection
+    from cafe_amd.sketch import HotSketch
+    others = [HotSketch(200 + i, 2, 1, 1.0, 1) for i in range(40)]
+    for i, sk in enumerate(others):
+        sk.insert_val(np.arange(1, 65, dtype=np.int64) + i, np.ones(64, np.float32))
+    F, dim, thr, B, hotn = 4, 16, 2, 8192, 1200
+    counts = [40000, 9000, 70000, 3000]
+    hash_sizes = [211, 37, 499, 13]
+    coll = CafeEmbeddingCollection(counts, dim, hotn, hash_sizes, threshold=thr, adjust_thres=1, alpha=1.0000005, seed=6)
+    coll.sketch.set_option("split_update", 2)
+    cpu = _CpuPipeline(oracle_mod, coll, thr, 1, 1.0000005)
+    rng = np.random.default_rng(29)
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    batches, grads = [], []
+    for step in range(6):
+        ids = np.stack([(rng.zipf(1.15, size=B) - 1 + step * 11) % c for c in counts]).astype(np.int64)
+        ids[0] = np.maximum(ids[0], 1)
+        batches.append(ids); grads.append(torch.randn(F, B, dim, device="cuda", generator=gen))
+    _run_steps(coll, cpu, oracle_mod, batches, grads, hint=True)
+    torch.cuda.synchronize()
+    for i, sk in enumerate(others):          # the small handles are still alive and answer
+        assert int((sk.query(np.arange(1, 65, dtype=np.int64) + i) != 0).sum()) == 64
+    for sk in others:
+        sk.close()
