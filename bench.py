@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-hint", action="store_true",
                     help="do NOT name the next step's id batch before the update (cafe_forward_hint_dev): the next gather is "
                          "then queued only after the host has seen the insert's verdict and returned")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the two extra measurements of the N = 1 line: the same step through 26 SKEmbeddingBag modules + "
+                         "torch.optim.SGD (the reference driver's call order), and CafeCTRModel.train_step with a DLRM head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -166,6 +169,82 @@ def run_cpu_baseline(args):
 
 
 # --------------------------------------------------------------------------------------------------
+# Extra keys of the N = 1 line (not `value`): what the same workload costs (a) through the drop-in module path -- one
+# SKEmbeddingBag per field, torch sparse gradients, torch.optim.SGD, in the call order of dlrm_s_pytorch.py:613-659
+# (apply_emb), :734-738 (insert_grad per field), :1658 (optimizer.step) -- and (b) as a whole training step of the thin DLRM
+# driver (CafeCTRModel.train_step: bottom MLP, dot interaction, top MLP, BCE loss in the loop), with and without the next
+# step's ids named ahead.  Short runs on a sketch that is still filling: orders of magnitude, not tuned figures.
+# --------------------------------------------------------------------------------------------------
+def run_extras(args, wl, ids_dev, grad):
+    import torch
+    from cafe_amd.sketch import HotSketch
+    from cafe_amd.sk_embedding_bag import SKEmbeddingBag
+    from cafe_amd.ctr_models import CafeCTRModel
+    F, B, D = wl.num_fields, wl.batch, wl.dim
+    out = {}
+    nb = len(ids_dev)
+
+    def timed(fn, warm, steps):
+        for i in range(warm):
+            fn(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(warm + i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    try:
+        lib = HotSketch(wl.hotn, wl.threshold, 1, wl.alpha, 1)
+        w_high = torch.nn.Parameter(torch.zeros(wl.hotn, D, device="cuda"))
+        mods = [SKEmbeddingBag(f, wl.hotn, lib, w_high, "cuda", wl.counts[f], D, int(wl.offsets[f]), wl.hash_sizes[f]).cuda()
+                for f in range(F)]
+        opt = torch.optim.SGD([w_high] + [m.weight_hash for m in mods], lr=args.lr)
+        offs = torch.arange(B, device="cuda")
+        gs = [grad[f] for f in range(F)]
+
+        def mstep(i):
+            ids = ids_dev[i % nb]
+            opt.zero_grad(set_to_none=True)
+            outs = [m(ids[f], offs) for f, m in enumerate(mods)]
+            torch.autograd.backward(outs, gs)
+            for f, m in enumerate(mods):
+                m.insert_grad(ids[f])
+            opt.step()
+        dt = timed(mstep, 60, 40)
+        out["module_path"] = {"what": f"{F} SKEmbeddingBag modules + torch.optim.SGD, one sketch call per field "
+                                      "(dlrm_s_pytorch.py:613-659, 734-738, 1658)",
+                              "ms_per_step": round(dt * 1e3, 3), "lookups_per_s": round(F * B / dt, 1)}
+        del mods, opt, w_high
+        lib.close()
+    except Exception as e:          # extras never cost the main result
+        out["module_path"] = {"error": repr(e)[:200]}
+    try:
+        # bench/criteo_terabyte.sh:20-29 and bench/criteo_kaggle.sh:20-28 (the top MLP's input width is the model's to fill in)
+        ln_bot, ln_top = ([13, 512, 256, D], [0, 1024, 1024, 512, 256, 1]) if D >= 64 else ([13, 512, 256, 64, D], [0, 512, 256, 1])
+        model = CafeCTRModel("dlrm", wl.counts, D, 13, wl.compress_rate, wl.hash_rate, wl.threshold, 1, wl.alpha,
+                             ln_bot=ln_bot, ln_top=ln_top)
+        opt = torch.optim.SGD(model.dense_parameters(), lr=args.lr)
+        dense = torch.rand(B, 13, device="cuda")
+        labels = (torch.rand(B, device="cuda") < 0.25).float()
+        if labels.dim() != 1:
+            labels = labels.reshape(-1)
+
+        def estep(i, hint):
+            model.train_step(dense, ids_dev[i % nb], labels, opt, args.lr, next_ids=ids_dev[(i + 1) % nb] if hint else None)
+        lab_shape = model.forward(dense, ids_dev[0]).shape
+        labels = labels.reshape(lab_shape)
+        dt0 = timed(lambda i: estep(i, False), 100, 50)
+        dt1 = timed(lambda i: estep(i, True), 20, 50)
+        out["e2e_dlrm_train_step"] = {"what": f"CafeCTRModel('dlrm') bot {'-'.join(map(str, ln_bot))}, top {'-'.join(map(str, ln_top[1:]))}, "
+                                              f"batch {B}: forward, BCE loss, backward, fused embedding update, SGD on the head",
+                                      "ms_per_step": round(dt0 * 1e3, 3), "ms_per_step_next_ids_named": round(dt1 * 1e3, 3),
+                                      "lookups_per_s": round(F * B / min(dt0, dt1), 1)}
+    except Exception as e:
+        out["e2e_dlrm_train_step"] = {"error": repr(e)[:200]}
+    return out
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
@@ -379,6 +458,8 @@ def main():
         }
         if roof:
             res["roofline"] = roof
+        if world == 1 and not args.no_extras:
+            res["extras"] = run_extras(args, wl, ids_dev, grad)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = run_cpu_baseline(args)
         print(json.dumps(res), flush=True)

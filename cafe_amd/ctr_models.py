@@ -138,7 +138,7 @@ class _Lookup(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, owner, ids):
         ctx.owner = owner
-        return owner.embedding.forward(ids)
+        return owner.embedding.forward(ids, out=owner._lookup_out(ids, 0))
 
     @staticmethod
     def backward(ctx, g):
@@ -198,17 +198,35 @@ class CafeCTRModel(nn.Module):
         emb = torch.cat([sk, pl]).index_select(0, self._order.to(sk.device))
         return self.head(dense, emb)
 
+    def _lookup_out(self, ids, ahead):
+        """Two output arrays used by alternate steps (ahead = 1: the one the NEXT forward will write), so that the next
+        step's forward can be named while this step's update is being queued (CafeEmbeddingCollection.hint_next)."""
+        shape = (ids.shape[0], ids.shape[1], self.dim)
+        outs = getattr(self, "_outs", None)
+        if outs is None or outs[0].shape != torch.Size(shape):
+            outs = [torch.empty(shape, device=self.embedding.device) for _ in range(2)]
+            self._outs, self._out_at = outs, 0
+        if not ahead:
+            self._out_at ^= 1
+            return self._outs[self._out_at]
+        return self._outs[self._out_at ^ 1]
+
     def dense_parameters(self):
         """What torch's optimizer updates: the head and the plain tables of fields too small for the sketch."""
         return list(self.head.parameters()) + list(self.plain.parameters())
 
-    def train_step(self, dense, ids, labels, optimizer, lr):
+    def train_step(self, dense, ids, labels, optimizer, lr, next_ids=None):
         """One step in the reference's order (dlrm_s_pytorch.py:1640-1658): forward, backward, insert_grad, SGD.
-        `optimizer` holds dense_parameters(); the sketch-backed tables are updated by the fused backward.  Returns the loss."""
+        `optimizer` holds dense_parameters(); the sketch-backed tables are updated by the fused backward.  Returns the loss.
+        next_ids: the next step's ids when the data loader has them already (contiguous [F, B] int64 on the device, all
+        fields sketch fields): that step's embedding forward is then queued behind this step's update before the host
+        waits for the device's verdict on the insert (cafe_forward_hint_dev)."""
         optimizer.zero_grad(set_to_none=True)
         p = self.forward(dense, ids)
         loss = self.loss_fn(p, labels)
         loss.backward()
+        if next_ids is not None and not self.plain_idx:
+            self.embedding.hint_next(next_ids, self._lookup_out(next_ids, 1))
         self.embedding.backward_update(self._emb_grad, lr, per_field_calls=self.per_field_calls)
         self._emb_grad = None
         optimizer.step()
