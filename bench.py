@@ -449,6 +449,8 @@ def main():
                        # snapshot); with next_ids_hint the next gather is queued before that wait
                        "host_syncs_in_step": 1 if world == 1 else getattr(eng, "host_syncs_in_step", 0),
                        "next_ids_hint": int(use_hint),
+                       "host_waits_for_split_sizes": ({"count": eng.host_syncs_total, "ms_total": round(eng.host_wait_ms, 3)}
+                                                      if world > 1 else None),
                        "ids_ready": int(world == 1 and not args.ids_on_stream),
                        "preheat_steps": args.preheat, "id_batches": nb, "drift": args.drift, "repetitions": reps,
                        "cadence_miss": (eng.sketch.counters()["cadence_miss"] if getattr(eng, "sketch", None) else None)},

@@ -345,8 +345,9 @@ struct ScoreSrc {
     const float *vals;
     const float *fsum;      // per-field sums (global or LDS), or nullptr
     int seg;
+    int stride = 1;         // floats between two scores (a score column inside packed rows: cafe_backward_update_gid_dev)
     __device__ float at(uint32_t i) const {
-        float c = vals ? vals[i] : 1.0f;
+        float c = vals ? vals[(size_t)i * (size_t)stride] : 1.0f;
         if (fsum) c = c * (float)seg / fsum[i / (uint32_t)seg];
         return c;
     }

@@ -269,7 +269,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     // when forwards come without updates (inference), resumed by the next cafe_backward_update_dev.
     bool plan = false, plan_launched = false;
     if (total >= 32768 && s->opt_overlap && cafe::ensure_streams(s)) return 1;
-    if (d_local_ids && s->opt_plan_ahead && s->opt_overlap && !s->opt_serial && s->opt_fuse_fields && s->side_stream &&
+    if ((d_local_ids || d_in_gids) && s->opt_plan_ahead && s->opt_overlap && !s->opt_serial && s->opt_fuse_fields && s->side_stream &&
         s->side_stream != st && total >= 32768 && total <= cafe::kParMaxIds && t->num_fields <= kMaxSeg) {
         if (s->plan_valid) s->unused_plans++;
         s->plan_valid = 0;
@@ -287,10 +287,10 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
                 // behind the commit kernel of the insert just queued (its completion signal), beside the migration, the
                 // row updates and this gather
                 CAFE_HIP_CHECK(hipStreamWaitEvent(s->side_stream, s->ev_commit, 0));
-                if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream)) return 1;
+                if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream, d_in_gids)) return 1;
                 plan_launched = true;
             } else if (s->opt_ids_ready && s->call_seq == s->base_seq) {
-                if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream)) return 1;
+                if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream, d_in_gids)) return 1;
                 plan_launched = true;
             } else {
                 CAFE_HIP_CHECK(hipEventRecord(s->ev_head_fork, st));
@@ -324,14 +324,14 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     if (t->timing) (void)hipEventRecord(t->ev_t[0][1], st);
     CAFE_HIP_CHECK(hipGetLastError());
     if (plan && !plan_launched) {
-        if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream)) return 1;
+        if (cafe::par_plan_ahead(s, d_local_ids, t->d_id_offset, batch, total, s->side_stream, d_in_gids)) return 1;
     }
     if (plan && want_split_update(s, t, total)) {
         // The partition passes of the update that will follow read nothing but this gather's routing: they run right
         // behind it on the third stream (in a training step: under the dense model's forward and backward), and the
         // gradient pass of the split update follows them there without a cross-stream hand-over.
         CAFE_HIP_CHECK(hipStreamWaitEvent(s->low_stream, s->ev_fwd, 0));
-        if (backward_common(t, nullptr, d_que, nullptr, batch, total, 0.f, st, s->low_stream, 17)) return 1;
+        if (backward_common(t, d_fields, d_que, nullptr, batch, total, 0.f, st, s->low_stream, 17)) return 1;
         t->bwd_plan_que = d_que;
         t->bwd_plan_fwd = s->fwd_count;
     }
@@ -1355,16 +1355,49 @@ extern "C" int cafe_backward_sgd_gid_strided_dev(cafe_tables_t *t, const int32_t
 //
 // The migration and the SGD update are queued behind the insert before the host waits for the verdict, so the device
 // does not idle; both do nothing if the device rejected the insert (the host then repeats them behind the repair).
-extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
-                                        const int32_t *d_que, const float *d_grad_out, int batch, float lr, float *d_scores,
-                                        int32_t *d_ins, int per_field, cafe_stream_t stream) {
+// One step of the owner-side work, in either layout: lookups in field-major order with per-field ids (the single-GPU
+// collection: field = position / batch, scores = norms of the gradient rows scaled per field), or lookups in arbitrary
+// order with a field each and their scores given (a shard of the multi-GPU path: gradient rows `gstride` floats apart,
+// the score of a lookup at scores_in[i * scores_stride]).
+struct StepArgs {
+    const int64_t *local_ids = nullptr;
+    const int32_t *gids = nullptr, *fields = nullptr, *que = nullptr;
+    const float *grad = nullptr;
+    int gstride = 0;                    // 0: rows are dim floats apart
+    int batch = 1, total = 0;
+    float lr = 0.f;
+    const float *scores_in = nullptr;
+    int scores_stride = 1;
+    float *scores_out = nullptr;
+    int32_t *ins = nullptr;
+    int per_field = 0;
+    const char *who = "cafe_backward_update_dev";
+};
+
+__global__ void k_strided_copy(const float *__restrict__ src, int stride, int n, float *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[(size_t)i * stride];
+}
+
+static int step_common(cafe_sketch_t *s, cafe_tables_t *t, const StepArgs &a, cafe_stream_t stream) {
+    const int64_t *d_local_ids = a.local_ids;
+    const int32_t *d_gids = a.gids, *d_fields = a.fields, *d_que = a.que;
+    const float *d_grad_out = a.grad, *scores_in = a.scores_in;
+    const int batch = a.batch, gstride = a.gstride, per_field = a.per_field;
+    const float lr = a.lr;
+    float *d_scores = a.scores_out;
+    int32_t *d_ins = a.ins;
     const int F = t->num_fields;
-    const int total = F * batch;
+    const int total = a.total;
     hipStream_t st = (hipStream_t)stream;
     if (total <= 0) return 0;
-    if (pair_ok(s, t, "cafe_backward_update_dev")) return 1;
-    const bool cadence = per_field && F > 1;
-    bool fuse = F <= kMaxSeg && s->opt_fuse_fields && !s->opt_serial && total <= cafe::kParMaxIds;
+    if (pair_ok(s, t, a.who)) return 1;
+    const bool cadence = per_field && F > 1 && !d_fields;
+    // a place for the scores when the caller does not ask for them (the call-by-call paths read them back)
+    const size_t norm_floats = (size_t)total + (size_t)F * kMaxNormParts;
+    if (t->ws_norm.reserve(norm_floats * 4 + 16)) return 1;
+    if (scores_in && !d_scores) d_scores = t->ws_norm.as<float>();
+    bool fuse = (scores_in || F <= kMaxSeg) && s->opt_fuse_fields && !s->opt_serial && total <= cafe::kParMaxIds;
     if (fuse) {
         double d = s->decay;
         for (int f = 0; f < (cadence ? F : 1); ++f) {                    // sketch.cpp:284-289 for the calls ahead
@@ -1384,8 +1417,7 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
         hipStream_t side = st;
         if (s->opt_overlap && total >= 32768 && cafe::ensure_streams(s)) return 1;
         if (s->opt_overlap && s->side_stream && s->side_stream != st && total >= 32768) side = s->side_stream;
-        const size_t norm_floats = (size_t)total + (size_t)F * kMaxNormParts;
-        if (t->ws_norm.reserve(norm_floats * 4 + 16) || cafe::par_prepare(s, total)) return 1;
+        if (cafe::par_prepare(s, total)) return 1;
         float *gn = t->ws_norm.as<float>(), *psum = gn + total;
         const double decay0 = s->decay;
         const int batch_num0 = s->batch_num;
@@ -1419,31 +1451,38 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             const bool early = split && attempt == 0 && s->fwd_que == d_que && t->bwd_plan_que == d_que && t->bwd_plan_fwd == s->fwd_count;
             if (early) plan_done = true;
             if (attempt == 0) {
-                if (t->timing) { (void)hipEventRecord(t->ev_t[3][0], st); t->ev_epoch[3] = t->bwd_epoch; }
-                if (norms_common(t, d_grad_out, batch, gn, psum, &nparts, st, split ? s->ev_gn : nullptr)) return 1;
-                if (t->timing) (void)hipEventRecord(t->ev_t[3][1], st);
+                if (!scores_in) {
+                    if (t->timing) { (void)hipEventRecord(t->ev_t[3][0], st); t->ev_epoch[3] = t->bwd_epoch; }
+                    if (norms_common(t, d_grad_out, batch, gn, psum, &nparts, st, split ? s->ev_gn : nullptr)) return 1;
+                    if (t->timing) (void)hipEventRecord(t->ev_t[3][1], st);
+                } else if (split) {
+                    CAFE_HIP_CHECK(hipEventRecord(s->ev_gn, st));        // the gradient is complete at this point of `st`
+                }
                 if (early) {
                     // the gradient pass behind them, once the norm kernel (which read the same gradient) is complete
                     CAFE_HIP_CHECK(hipStreamWaitEvent(s->low_stream, s->ev_gn, 0));
-                    if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, s->low_stream, s->low_stream, 4)) return 1;
+                    if (backward_common(t, d_fields, d_que, d_grad_out, batch, total, lr, s->low_stream, s->low_stream, 4, nullptr, 0, gstride)) return 1;
                     sums_done = true;
                 }
-            } else {
+            } else if (!scores_in) {
                 int rows;
                 norm_geometry(batch, &nparts, &rows);
             }
             s->seg_len = cadence ? batch : 0;
             s->score_seg = batch;
             s->verify_mode = 1;
-            s->plan_expect = d_local_ids;
+            s->plan_expect = d_local_ids ? (const void *)d_local_ids : (const void *)d_gids;
+            s->score_stride = scores_in ? a.scores_stride : 0;
             s->unused_plans = 0;
             if (t->timing) { s->ev_chain[0] = t->ev_t[2][0], s->ev_chain[1] = t->ev_t[2][1]; t->ev_epoch[2] = t->bwd_epoch; }
             // the insert's commit copies the rows of the ids that take a slot itself (sk_embedding_bag.py:199-208)
             s->mig.w_hot = t->d_w_hot; s->mig.w_cold = t->d_w_cold; s->mig.hash_size = t->d_hash_size; s->mig.local_ids = d_local_ids;
             s->mig.batch = batch; s->mig.dim = t->dim; s->mig.hotn = t->hotn;
+            s->mig.gids = d_gids; s->mig.fields = d_fields; s->mig.id_offset = t->d_id_offset;
             s->mig_done = 0;
-            const int rc = cafe::insert_dev_on(s, d_gids, gn, psum, nparts, total, d_ins, d_scores, st,
-                                               (s->opt_overlap & 1) && !simple ? side : st);
+            const int rc = cafe::insert_dev_on(s, d_gids, scores_in ? scores_in : gn, scores_in ? nullptr : psum, nparts, total, d_ins,
+                                               d_scores, st, (s->opt_overlap & 1) && !simple ? side : st);
+            s->score_stride = 0;
             const uint32_t my_seq = s->call_seq;
             s->mig.w_hot = nullptr;
             s->seg_len = 0; s->score_seg = 0; s->verify_mode = 0; s->plan_expect = nullptr;
@@ -1454,27 +1493,30 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
                 // stay behind the migration: a migrated row is copied before it is updated, and hot rows are not disjoint
                 // from migration targets after a reset.  Run beside the insert as a whole, the update slowed the insert's
                 // latency-bound kernels by more than it saved; its gradient pass alone -- the split form -- pays.)
-                if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, side, split ? 17 : 1)) return 1;
+                if (backward_common(t, d_fields, d_que, d_grad_out, batch, total, lr, st, side, split ? 17 : 1, nullptr, 0, gstride)) return 1;
                 plan_done = true;
                 if (split) {
                     // The gradient pass (segment sums; tables untouched) on the low-priority stream: behind the norm
                     // kernel (which read the same gradient: it is complete) and the partition passes.  It runs while the
                     // insert's latency-bound kernels leave the memory system idle; the row updates follow the migration.
                     CAFE_HIP_CHECK(hipStreamWaitEvent(s->low_stream, s->ev_gn, 0));
-                    if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, s->low_stream, side, 4)) return 1;
+                    if (backward_common(t, d_fields, d_que, d_grad_out, batch, total, lr, s->low_stream, side, 4, nullptr, 0, gstride)) return 1;
                     sums_done = true;
                 }
             }
-            if (!s->mig_done && migrate_list(s, t, d_local_ids, d_gids, d_ins, batch, st)) return 1;
-            if (backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st,
+            if (!s->mig_done) {
+                if (d_local_ids ? migrate_list(s, t, d_local_ids, d_gids, d_ins, batch, st)
+                                : cafe_migrate_gid_dev(s, t, d_gids, d_fields, d_ins, total, stream)) return 1;
+            }
+            if (backward_common(t, d_fields, d_que, d_grad_out, batch, total, lr, st,
                                 simple ? st : sums_done ? s->low_stream : plan_done ? side : st,
-                                simple ? 3 : sums_done ? 8 : plan_done ? 2 : 3, &s->d_state->rejected_seq, my_seq)) return 1;
+                                simple ? 3 : sums_done ? 8 : plan_done ? 2 : 3, &s->d_state->rejected_seq, my_seq, gstride)) return 1;
             // The forward the caller has named as its next call goes in here, before the host waits: the gather behind the
             // row updates on `st`, its plan behind the commit kernel on the second stream, so the device never waits for
             // the host between two steps.  Same batch size only (no workspace may grow under the kernels in flight).
             bool spec = false;
             cafe_sketch::Hint &h = s->hint;
-            if (attempt == 0 && h.valid && !h.enqueued && h.t == t && h.st == st && h.batch == batch && h.que != d_que &&
+            if (attempt == 0 && d_local_ids && h.valid && !h.enqueued && h.t == t && h.st == st && h.batch == batch && h.que != d_que &&
                 h.gids != d_gids) {
                 if (forward_common(s, t, h.ids, nullptr, nullptr, batch, (long)total, h.gids, h.que, h.out, st, true)) return 1;
                 h.enqueued = 1;
@@ -1492,19 +1534,19 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
                     // is reported to the named file with the state of every stream and event it uses, and the call fails
                     const double t_dbg = now_us();
                     for (;;) {
-                        const hipError_t a = hipStreamQuery(st), b = s->low_stream ? hipStreamQuery(s->low_stream) : hipSuccess;
-                        if (a == hipSuccess && b == hipSuccess) break;
+                        const hipError_t qa = hipStreamQuery(st), b = s->low_stream ? hipStreamQuery(s->low_stream) : hipSuccess;
+                        if (qa == hipSuccess && b == hipSuccess) break;
                         if (now_us() - t_dbg > 10e6) {
                             auto name = [](hipError_t e) { return e == hipSuccess ? "done" : e == hipErrorNotReady ? "busy" : "error"; };
                             if (FILE *dbg = fopen(report, "w")) {
                                 fprintf(dbg, "step %u does not finish: caller's stream %s, second stream %s, third stream %s | events: norms %s, "
                                         "gather %s, partition passes %s, segment sums %s | split %d sums queued %d partition passes queued %d\n",
-                                        s->call_seq, name(a), name(hipStreamQuery(s->side_stream)), name(b), name(hipEventQuery(s->ev_gn)),
+                                        s->call_seq, name(qa), s->side_stream ? name(hipStreamQuery(s->side_stream)) : "-", name(b), name(hipEventQuery(s->ev_gn)),
                                         name(hipEventQuery(s->ev_fwd)), t->ev_plan ? name(hipEventQuery(t->ev_plan)) : "-",
                                         t->ev_sums ? name(hipEventQuery(t->ev_sums)) : "-", (int)split, (int)sums_done, (int)plan_done);
                                 fclose(dbg);
                             }
-                            set_error("cafe_backward_update_dev: step %u does not finish (report in %s)", s->call_seq, report);
+                            set_error("%s: step %u does not finish (report in %s)", a.who, s->call_seq, report);
                             return 1;
                         }
                     }
@@ -1546,17 +1588,135 @@ extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, cons
             const size_t o = cadence ? (size_t)f * batch : 0;
             const int nn = cadence ? batch : total;
             if (cafe_insert_dev(s, d_gids + o, d_scores + o, nn, d_ins + o, stream)) return 1;
-            if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, cadence ? f : 0, cadence ? 1 : F, stream)) return 1;
+            if (d_local_ids ? cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, cadence ? f : 0, cadence ? 1 : F, stream)
+                            : cafe_migrate_gid_dev(s, t, d_gids, d_fields, d_ins, total, stream)) return 1;
         }
-        if (simple) return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, st, 3);
-        return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, sums_done ? s->low_stream : side, sums_done ? 8 : 2);
+        if (simple) return backward_common(t, d_fields, d_que, d_grad_out, batch, total, lr, st, st, 3, nullptr, 0, gstride);
+        return backward_common(t, d_fields, d_que, d_grad_out, batch, total, lr, st, sums_done ? s->low_stream : side, sums_done ? 8 : 2,
+                               nullptr, 0, gstride);
     }
-    if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) return 1;
+    if (scores_in) {
+        hipLaunchKernelGGL(k_strided_copy, dim3((total + 255) / 256), dim3(256), 0, st, scores_in, a.scores_stride, total, d_scores);
+        CAFE_HIP_CHECK(hipGetLastError());
+    } else if (cafe_scores_dev(t, d_grad_out, batch, d_scores, stream)) {
+        return 1;
+    }
     for (int f = 0; f < (cadence ? F : 1); ++f) {
         const size_t o = cadence ? (size_t)f * batch : 0;
         const int nn = cadence ? batch : total;
         if (cafe_insert_dev(s, d_gids + o, d_scores + o, nn, d_ins + o, stream)) return 1;
-        if (cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, cadence ? f : 0, cadence ? 1 : F, stream)) return 1;
+        if (d_local_ids ? cafe_migrate_dev(s, t, d_local_ids, d_gids, d_ins, batch, cadence ? f : 0, cadence ? 1 : F, stream)
+                        : cafe_migrate_gid_dev(s, t, d_gids, d_fields, d_ins, total, stream)) return 1;
     }
-    return backward_common(t, nullptr, d_que, d_grad_out, batch, total, lr, st, st);
+    return backward_common(t, d_fields, d_que, d_grad_out, batch, total, lr, st, st, 3, nullptr, 0, gstride);
+}
+
+extern "C" int cafe_backward_update_dev(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_local_ids, const int32_t *d_gids,
+                                        const int32_t *d_que, const float *d_grad_out, int batch, float lr, float *d_scores,
+                                        int32_t *d_ins, int per_field, cafe_stream_t stream) {
+    StepArgs a;
+    a.local_ids = d_local_ids; a.gids = d_gids; a.que = d_que; a.grad = d_grad_out; a.batch = batch;
+    a.total = t->num_fields * batch; a.lr = lr; a.scores_out = d_scores; a.ins = d_ins; a.per_field = per_field;
+    return step_common(s, t, a, stream);
+}
+
+// The same step for a shard of the multi-GPU path (no reference counterpart): n lookups in arbitrary order,
+// each with its global id, its field and its routing word, their gradient rows `row_stride` floats apart in d_rows with
+// the lookup's score at column `dim` of its row (read in place).  ONE batch_insert_val over the n ids in the order
+// given, migration, SGD -- as one parallel insert with the device's verdict, the plan made beside the forward
+// (cafe_forward_gid_dev), the update split by the library's rule, exactly like cafe_backward_update_dev.
+extern "C" int cafe_backward_update_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_fields,
+                                            const int32_t *d_que, const float *d_rows, int row_stride, int n, float lr,
+                                            int32_t *d_ins, cafe_stream_t stream) {
+    if (row_stride < t->dim + 1 || (row_stride & 3)) {
+        set_error("cafe_backward_update_gid_dev: row stride %d must be a multiple of 4 and larger than dim = %d", row_stride, t->dim);
+        return 1;
+    }
+    if (n < 0 || !d_fields) { set_error("cafe_backward_update_gid_dev: bad arguments"); return 1; }
+    StepArgs a;
+    a.gids = d_gids; a.fields = d_fields; a.que = d_que; a.grad = d_rows; a.gstride = row_stride; a.batch = 1; a.total = n;
+    a.lr = lr; a.scores_in = d_rows + t->dim; a.scores_stride = row_stride; a.ins = d_ins; a.per_field = 0;
+    a.who = "cafe_backward_update_gid_dev";
+    return step_common(s, t, a, stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The two permutations of the multi-GPU exchange (cafe_amd/sharded.py; no reference counterpart), one launch each
+// instead of a zero-fill and indexed copies: the send buffer of the backward all-to-all, rows [gradient row | score | 0 0 0]
+// in destination order, with the score formed here (sk_embedding_bag.py:189 over the global batch: norm * scale / field
+// sum); and the rows that came back from the owners, put where their lookups are.
+// ------------------------------------------------------------------------------------------------
+template <int LPG>
+__global__ void __launch_bounds__(256) k_pack_rows(const float *__restrict__ grad, const float *__restrict__ norms,
+                                                   const float *__restrict__ fsums, float scale, int batch,
+                                                   const int64_t *__restrict__ order, int n, int dim, float *__restrict__ out,
+                                                   float *__restrict__ scores) {
+    const int groups = (gridDim.x * blockDim.x) / LPG, gi = (blockIdx.x * blockDim.x + threadIdx.x) / LPG, lig = threadIdx.x % LPG;
+    const int dim4 = dim >> 2, row4 = dim4 + 1;
+    for (int j = gi; j < n; j += groups) {
+        const int64_t i = order[j];
+        const float4 *src = reinterpret_cast<const float4 *>(grad + (size_t)i * dim);
+        float4 *dst = reinterpret_cast<float4 *>(out + (size_t)j * (dim + 4));
+        for (int c = lig; c < dim4; c += LPG) cafe::store_through16(&dst[c], src[c]);
+        if (lig == 0) {
+            const float sc = norms[i] * scale / fsums[i / batch];
+            cafe::store_through16(&dst[row4 - 1], make_float4(sc, 0.f, 0.f, 0.f));
+            if (scores) scores[i] = sc;
+        }
+    }
+}
+
+template <int LPG>
+__global__ void __launch_bounds__(256) k_unpack_rows(const float *__restrict__ back, const int64_t *__restrict__ order, int n,
+                                                     int dim, float *__restrict__ out) {
+    const int groups = (gridDim.x * blockDim.x) / LPG, gi = (blockIdx.x * blockDim.x + threadIdx.x) / LPG, lig = threadIdx.x % LPG;
+    const int dim4 = dim >> 2;
+    for (int j = gi; j < n; j += groups) {
+        const float4 *src = reinterpret_cast<const float4 *>(back + (size_t)j * dim);
+        float4 *dst = reinterpret_cast<float4 *>(out + (size_t)order[j] * dim);
+        for (int c = lig; c < dim4; c += LPG) cafe::store_through16(&dst[c], src[c]);
+    }
+}
+
+extern "C" int cafe_pack_rows_dev(const float *d_grad, const float *d_norms, const float *d_field_sums, float scale, int batch,
+                                  const int64_t *d_order, int n, int dim, float *d_out, float *d_scores, cafe_stream_t stream) {
+    if (n <= 0) return 0;
+    if (dim <= 0 || (dim & 3) || batch <= 0) { set_error("cafe_pack_rows_dev: bad sizes (dim %d, batch %d)", dim, batch); return 1; }
+    const int lpg = lanes_per_row(dim);
+    const int blocks = std::min((n + 256 / lpg - 1) / (256 / lpg), 256 * 16);
+#define CAFE_PK(L) hipLaunchKernelGGL(k_pack_rows<L>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_grad, d_norms, d_field_sums, scale, \
+                                      batch, d_order, n, dim, d_out, d_scores)
+    switch (lpg) {
+        case 1: CAFE_PK(1); break;
+        case 2: CAFE_PK(2); break;
+        case 4: CAFE_PK(4); break;
+        case 8: CAFE_PK(8); break;
+        case 16: CAFE_PK(16); break;
+        case 32: CAFE_PK(32); break;
+        default: CAFE_PK(64); break;
+    }
+#undef CAFE_PK
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int cafe_unpack_rows_dev(const float *d_back, const int64_t *d_order, int n, int dim, float *d_out, cafe_stream_t stream) {
+    if (n <= 0) return 0;
+    if (dim <= 0 || (dim & 3)) { set_error("cafe_unpack_rows_dev: bad dim %d", dim); return 1; }
+    const int lpg = lanes_per_row(dim);
+    const int blocks = std::min((n + 256 / lpg - 1) / (256 / lpg), 256 * 16);
+#define CAFE_UP(L) hipLaunchKernelGGL(k_unpack_rows<L>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_back, d_order, n, dim, d_out)
+    switch (lpg) {
+        case 1: CAFE_UP(1); break;
+        case 2: CAFE_UP(2); break;
+        case 4: CAFE_UP(4); break;
+        case 8: CAFE_UP(8); break;
+        case 16: CAFE_UP(16); break;
+        case 32: CAFE_UP(32); break;
+        default: CAFE_UP(64); break;
+    }
+#undef CAFE_UP
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
 }

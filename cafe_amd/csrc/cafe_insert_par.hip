@@ -172,6 +172,7 @@ struct IdSrc {
 struct Score {
     const float *vals;      // [n] scores or norms; nullptr: every score is 1 (batch_insert)
     const float *psum;      // [F][nparts] partial sums of the norms per field, or nullptr
+    int vstride;            // floats between two entries of vals (1: contiguous)
 };
 
 // Diagnostic build (make EXTRA=-DCAFE_PROF): wave 0 of every round-1 workgroup stamps the 100 MHz wall clock at phase
@@ -703,7 +704,7 @@ __device__ inline void field_sums(const Geo &g, const Score &sc, float *fsum) {
 }
 __device__ inline ScoreSrc score_src(const Geo &g, const Score &sc, const float *fsum) {
     ScoreSrc s;
-    s.vals = sc.vals; s.fsum = sc.psum ? fsum : nullptr; s.seg = g.sseg;
+    s.vals = sc.vals; s.fsum = sc.psum ? fsum : nullptr; s.seg = g.sseg; s.stride = sc.vstride;
     return s;
 }
 
@@ -2014,7 +2015,9 @@ struct CommitArgs {
     float *w_hot;
     float *const *w_cold;
     const int32_t *hash_size;
-    const int64_t *local_ids;
+    const int64_t *local_ids;   // per-field ids in field-major order (field = position / batch), or nullptr:
+    const int32_t *mig_gids, *mig_fields;       // ... global ids with a field per lookup (local id = gid - id_offset[field])
+    const int64_t *id_offset;
     int batch, dim, hotn;
 };
 
@@ -2085,8 +2088,9 @@ __global__ void __launch_bounds__(256) k_commit(Geo g, CommitArgs A, Score sc) {
                 mk &= mk - 1ull;
                 const uint32_t pos = (uint32_t)__shfl(placeholder, l, 64) & ~kSur;
                 const uint32_t sl = (uint32_t)__shfl(slot, l, 64);
-                const int f = (int)(pos / (uint32_t)A.batch);
-                const int64_t src_row = A.local_ids[pos] % (int64_t)A.hash_size[f];
+                const int f = A.local_ids ? (int)(pos / (uint32_t)A.batch) : A.mig_fields[pos];
+                const int64_t local = A.local_ids ? A.local_ids[pos] : (int64_t)A.mig_gids[pos] - A.id_offset[f];
+                const int64_t src_row = local % (int64_t)A.hash_size[f];
                 const float4 *src = reinterpret_cast<const float4 *>(A.w_cold[f] + (size_t)src_row * A.dim);
                 float4 *dst = reinterpret_cast<float4 *>(A.w_hot + (size_t)(sl % (uint32_t)A.hotn) * A.dim);
                 for (int c = lane; c < dim4; c += 64) dst[c] = src[c];
@@ -2417,14 +2421,16 @@ static int launch_plan(cafe_sketch *s, Geo &g, const IdSrc &ids, hipStream_t pre
 
 // cafe_forward_dev: the plan of the insert that will follow this forward, on the handle's second stream beside the
 // gather kernel.  It stands if the next insert is over the same ids with no call, flip or reset in between.
-int par_plan_ahead(cafe_sketch *s, const int64_t *d_local_ids, const int64_t *d_id_offset, int batch, int n, hipStream_t side) {
+int par_plan_ahead(cafe_sketch *s, const int64_t *d_local_ids, const int64_t *d_id_offset, int batch, int n, hipStream_t side,
+                   const int32_t *d_gids) {
     Geo g;
     if (ensure_ws(s, n, g)) return 1;
     g.flip_now = 0;
     IdSrc ids;
-    ids.gids = nullptr; ids.local_ids = d_local_ids; ids.id_offset = d_id_offset; ids.batch = batch;
+    ids.gids = d_local_ids ? nullptr : d_gids; ids.local_ids = d_local_ids; ids.id_offset = d_id_offset; ids.batch = batch;
     if (launch_plan(s, g, ids, side, s->ev_plan)) return 1;
-    s->plan_valid = 1; s->plan_seq = s->call_seq; s->plan_n = n; s->plan_ids = d_local_ids; s->plan_flip = s->flip;
+    s->plan_valid = 1; s->plan_seq = s->call_seq; s->plan_n = n; s->plan_flip = s->flip;
+    s->plan_ids = d_local_ids ? (const void *)d_local_ids : (const void *)d_gids;
     s->plan_hot = s->opt_hot_bypass; s->plan_target = s->opt_target_items;
     return 0;
 }
@@ -2445,7 +2451,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     uint32_t *off = w.off.as<uint32_t>();
     Rec *rec1 = w.items.as<Rec>(), *rec2 = rec1 + n, *rech = rec2 + n;
     Score sc;
-    sc.vals = d_vals; sc.psum = d_psum;
+    sc.vals = d_vals; sc.psum = d_psum; sc.vstride = s->score_stride > 0 ? s->score_stride : 1;
 
     // ---- plan: the one made beside the forward, if it is still the plan of this call ----
     const bool ahead = s->plan_valid && s->plan_seq + 1 == s->call_seq && s->plan_n == n && s->plan_ids == s->plan_expect && !flip_now &&
@@ -2522,6 +2528,7 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     // batch walked in order by the closing workgroup has no staged placeholders to migrate from
     const bool mig = s->mig.w_hot != nullptr && g.verify;
     CA.w_hot = mig ? s->mig.w_hot : nullptr; CA.w_cold = s->mig.w_cold; CA.hash_size = s->mig.hash_size;
+    CA.mig_gids = s->mig.gids; CA.mig_fields = s->mig.fields; CA.id_offset = s->mig.id_offset;
     CA.local_ids = s->mig.local_ids; CA.batch = std::max(1, s->mig.batch); CA.dim = s->mig.dim; CA.hotn = std::max(1, s->mig.hotn);
     s->mig_done = mig ? 1 : 0;
     const int cb = g.P1 + g.P2 + (g.hot ? g.PH : 0);

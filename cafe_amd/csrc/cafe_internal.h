@@ -56,6 +56,7 @@ struct cafe_sketch {
     int force_cap = 0;                  // option "owner_cap": items an owner workgroup can hold (0 = chosen per call)
     int force_cap_once = 0;             // ... for the call being issued (a step issued again after a workspace limit)
     int score_seg = 0;                  // > 0: vals are norms, scaled per segment of score_seg ids (ScoreSrc)
+    int score_stride = 0;               // > 1: floats between two scores of the call being issued (a column of packed rows)
     hipEvent_t ev_chain[2] = {nullptr, nullptr};    // timing aid: recorded around round 1 .. commit of the next insert
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // workspaces
@@ -115,6 +116,8 @@ struct cafe_sketch {
         float *const *w_cold = nullptr;
         const int32_t *hash_size = nullptr;
         const int64_t *local_ids = nullptr;
+        const int32_t *gids = nullptr, *fields = nullptr;      // local_ids == nullptr: a field per lookup, local id = gid - offset
+        const int64_t *id_offset = nullptr;
         int batch = 0, dim = 0, hotn = 0;
     } mig;
     int mig_done = 0;
@@ -172,7 +175,9 @@ constexpr int kParMaxIds = 1 << 21;     // largest batch of the parallel insert 
 int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const float *d_psum, int nparts, int n,
                int32_t *d_ins, float *d_scores_out, int flip_now, hipStream_t st, hipStream_t pre);
 int par_prepare(cafe_sketch *s, int n);          // sizes the workspaces (may allocate: before any kernel of the call)
-int par_plan_ahead(cafe_sketch *s, const int64_t *d_local_ids, const int64_t *d_id_offset, int batch, int n, hipStream_t side);
+// (d_local_ids == nullptr: the ids are the global ids at d_gids, complete in memory)
+int par_plan_ahead(cafe_sketch *s, const int64_t *d_local_ids, const int64_t *d_id_offset, int batch, int n, hipStream_t side,
+                   const int32_t *d_gids = nullptr);
 void par_free(cafe_sketch *s);
 // what the last parallel insert leaves for the migration: number of newly hot lookups (0xffffffff: scan ins[]) and
 // their batch positions

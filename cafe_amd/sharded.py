@@ -11,9 +11,11 @@ per shard.
 
 Per step (data-parallel batch, B samples per rank):
     route     owner of every lookup, stable order by owner, counts exchanged, ids exchanged.  It depends on the ids
-              only, so `prefetch(next_ids)` runs it one step ahead on the exchange stream: the split sizes (which
-              torch.distributed wants on the host) are then read from a transfer that finished long ago, and the step
-              itself never waits for the host.
+              only, so `prefetch(next_ids)` queues its first half (owners, order, counts exchanged and copied to pinned
+              host memory) one step ahead on the exchange stream, WITHOUT making that stream wait for the compute stream
+              and without blocking the host.  torch.distributed wants the split sizes on the host: they are read at the
+              next forward, from a transfer that finished during the previous step; that wait (normally zero) and the
+              batches that were not prefetched at all are counted (host_syncs_in_step, host_wait_ms).
     forward   owners run the fused query+gather -> all_to_all(rows) back
     backward  per-field sums of gradient norms all-reduced (scores are normalised over the GLOBAL batch)
               -> ONE all_to_all of rows [gradient row | score | 3 pad floats] -> owners run insert / migration /
@@ -85,23 +87,35 @@ class HipShardBackend:
         return gn, sums
 
     def backward_gid(self, gids, fields, que, packed, lr):
-        """packed: [n, dim + PAD] float32, a lookup's gradient row with its score at column dim."""
+        """packed: [n, dim + PAD] float32, a lookup's gradient row with its score at column dim (read in place).  The
+        fused owner step: plan (made beside forward_gid), rounds, the device's verdict, migration, split or one-kernel
+        update -- the path the single-GPU collection runs (cafe_backward_update_gid_dev)."""
         n = gids.numel()
         ins = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-        scores = packed[:, self.dim].contiguous()
-        st = self._st()
-        _lib.check(self.L.cafe_insert_dev(self.sketch.h, self._p(gids), self._p(scores), n, self._p(ins), st), "cafe_insert_dev")
-        _lib.check(self.L.cafe_migrate_gid_dev(self.sketch.h, self.coll.tables, self._p(gids), self._p(fields), self._p(ins),
-                                               n, st), "cafe_migrate_gid_dev")
-        _lib.check(self.L.cafe_backward_sgd_gid_strided_dev(self.coll.tables, self._p(fields), self._p(que), self._p(packed),
-                                                            packed.shape[1], n, ctypes.c_float(lr), st),
-                   "cafe_backward_sgd_gid_strided_dev")
+        _lib.check(self.L.cafe_backward_update_gid_dev(self.sketch.h, self.coll.tables, self._p(gids), self._p(fields),
+                                                       self._p(que), self._p(packed), packed.shape[1], n, ctypes.c_float(lr),
+                                                       self._p(ins), self._st()), "cafe_backward_update_gid_dev")
         return ins[:n]
+
+    def pack(self, grad, gn, sums, scale, batch, order):
+        """Send buffer of the backward exchange, one launch: rows [gradient | score | 0 0 0] in destination order."""
+        n = order.numel()
+        send = torch.empty(n, self.dim + PAD, device=self.device)
+        scores = torch.empty(n, device=self.device)
+        _lib.check(self.L.cafe_pack_rows_dev(self._p(grad), self._p(gn), self._p(sums), ctypes.c_float(scale), batch,
+                                             self._p(order), n, self.dim, self._p(send), self._p(scores), self._st()),
+                   "cafe_pack_rows_dev")
+        return send, scores
+
+    def unpack(self, back, order, out):
+        """out[order[j]] = back[j], one launch."""
+        _lib.check(self.L.cafe_unpack_rows_dev(self._p(back), self._p(order), order.numel(), self.dim, self._p(out), self._st()),
+                   "cafe_unpack_rows_dev")
 
 
 class _Route:
     """Where the lookups of one batch go: computed from the ids alone (possibly one step ahead)."""
-    __slots__ = ("ids", "B", "order", "ss", "rs", "r_gids", "r_fields", "ready")
+    __slots__ = ("ids", "B", "order", "ss", "rs", "r_gids", "r_fields", "ready", "counts_host", "counts_ev", "packed")
 
 
 class _Pending:
@@ -140,7 +154,9 @@ class ShardedCafeEmbedding:
         self._fields = None
         self._route = None
         self.last_received = 0
-        self.host_syncs_in_step = 0        # times a step had to wait for split sizes (0 when every batch was prefetched)
+        self.host_syncs_in_step = 0        # batches routed inside their own step (not prefetched): the step waits for the host
+        self.host_syncs_total = 0          # every time the host waited for split sizes, prefetched batches included
+        self.host_wait_ms = 0.0            # ... and how long in total
         # collectives on a stream of their own (device tensors only; CPU tensors over gloo run inline)
         self._xs = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
@@ -172,9 +188,9 @@ class ShardedCafeEmbedding:
                                input_split_sizes=list(send_splits), group=self.group)
         return out
 
-    def _make_route(self, local_ids):
-        """Owner of every lookup, the counts and the ids exchanged; everything is queued on the current stream except
-        the read of the split sizes, which torch.distributed needs on the host."""
+    def _route_begin(self, local_ids):
+        """First half of the route, all queued on the current stream, nothing waited for: owner of every lookup, stable
+        order by owner, counts exchanged, both count vectors on their way to pinned host memory."""
         F, B = local_ids.shape
         n = F * B
         if self._fields is None or self._fields.numel() != n:
@@ -189,29 +205,45 @@ class ShardedCafeEmbedding:
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         r = _Route()
         r.ids, r.B, r.order = local_ids, B, order
+        r.packed = (self._fields[order].to(torch.int64) << 32) | (gids[order].to(torch.int64) & 0xFFFFFFFF)
+        r.counts_ev, r.ss, r.rs, r.ready = None, None, None, None
         if send_counts.is_cuda:
-            # both count vectors to pinned host memory without blocking; read at first use (ready.synchronize())
-            hs = torch.empty(2, self.world, dtype=send_counts.dtype, pin_memory=True)
-            hs[0].copy_(send_counts, non_blocking=True); hs[1].copy_(recv_counts, non_blocking=True)
-            ev = torch.cuda.Event(); ev.record()
-            ev.synchronize()               # (on the exchange stream when prefetched: the compute stream is not involved)
-            r.ss, r.rs = hs[0].tolist(), hs[1].tolist()
+            r.counts_host = torch.empty(2, self.world, dtype=send_counts.dtype, pin_memory=True)
+            r.counts_host[0].copy_(send_counts, non_blocking=True); r.counts_host[1].copy_(recv_counts, non_blocking=True)
+            r.counts_ev = torch.cuda.Event(); r.counts_ev.record()
         else:
             r.ss, r.rs = send_counts.tolist(), recv_counts.tolist()
-        packed = (self._fields[order].to(torch.int64) << 32) | (gids[order].to(torch.int64) & 0xFFFFFFFF)
-        got = self._a2a(packed, r.ss, r.rs)
+        return r
+
+    def _route_finish(self, r):
+        """Second half: the split sizes on the host (the one wait of the route; counted), then the ids to their owners."""
+        if r.ss is None:
+            import time
+            t0 = time.perf_counter()
+            r.counts_ev.synchronize()
+            self.host_wait_ms += (time.perf_counter() - t0) * 1e3
+            self.host_syncs_total += 1
+            r.ss, r.rs = r.counts_host[0].tolist(), r.counts_host[1].tolist()
+        got = self._a2a(r.packed, r.ss, r.rs)
         r.r_gids = (got & 0xFFFFFFFF).to(torch.int32)          # wraps to the int32 bit pattern
         r.r_fields = (got >> 32).to(torch.int32)
-        r.ready = None
         if self._xs is not None:
             r.ready = torch.cuda.Event(); r.ready.record()
         return r
 
-    def prefetch(self, local_ids):
-        """Route the NEXT batch now, on the exchange stream (the ids of a training step are known before the step): the
-        later forward(local_ids) of the same tensor then starts without any host synchronisation."""
-        with self._on_exchange_stream():
-            self._route = self._make_route(local_ids)
+    def prefetch(self, local_ids, ids_ready=True):
+        """Start the route of the NEXT batch now, on the exchange stream (the ids of a training step are known before
+        the step).  ids_ready (default): the id tensor is complete in memory -- a data loader's batch -- so the exchange
+        stream does not wait for the compute stream and the route runs beside the current step; False: it is the output
+        of work queued on the compute stream.  The host is not blocked here; the next forward(local_ids) of the same
+        tensor picks the route up."""
+        if self._xs is None:
+            self._route = self._route_begin(local_ids)
+            return
+        if not ids_ready:
+            self._xs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._xs):
+            self._route = self._route_begin(local_ids)
 
     # -- the step ----------------------------------------------------------------------------------
     def forward_async(self, local_ids, out=None):
@@ -221,8 +253,15 @@ class ShardedCafeEmbedding:
         r = self._route
         if r is None or r.ids is not local_ids:
             self.host_syncs_in_step += 1
-            r = self._make_route(local_ids)
-        elif r.ready is not None:
+            r = self._route_finish(self._route_begin(local_ids))
+        else:
+            if self._xs is not None:
+                with torch.cuda.stream(self._xs):
+                    self._route_finish(r)
+                r.packed.record_stream(self._xs)
+            else:
+                self._route_finish(r)
+        if r.ready is not None:
             torch.cuda.current_stream().wait_event(r.ready)
         self._route = None
         self.last_received = int(r.r_gids.numel())
@@ -231,7 +270,10 @@ class ShardedCafeEmbedding:
             out = torch.empty(F, B, self.dim, device=self.device)
         with self._on_exchange_stream():
             back = self._a2a(rows, r.rs, r.ss)
-            out.view(n, self.dim)[r.order] = back
+            if hasattr(self.backend, "unpack"):
+                self.backend.unpack(back, r.order, out)
+            else:
+                out.view(n, self.dim)[r.order] = back
             ev = None
             if self._xs is not None:
                 ev = torch.cuda.Event(); ev.record()
@@ -253,10 +295,13 @@ class ShardedCafeEmbedding:
         gn, sums = self.backend.grad_norm(grad_out, B)
         with self._on_exchange_stream():
             dist.all_reduce(sums, group=self.group)
-            scores = gn.view(F, B) * float(B * self.world) / sums[:, None]          # sk_embedding_bag.py:189, global batch
-            send = torch.zeros(n, D + PAD, device=self.device)
-            send[:, :D] = grad_out.view(n, D)[order]
-            send[:, D] = scores.reshape(-1)[order]
+            if hasattr(self.backend, "pack"):
+                send, scores = self.backend.pack(grad_out, gn, sums, float(B * self.world), B, order)
+            else:
+                scores = gn.view(F, B) * float(B * self.world) / sums[:, None]          # sk_embedding_bag.py:189, global batch
+                send = torch.zeros(n, D + PAD, device=self.device)
+                send[:, :D] = grad_out.view(n, D)[order]
+                send[:, D] = scores.reshape(-1)[order]
             packed = self._a2a(send, ss, rs)
             if self._xs is not None:
                 for t in (grad_out, gn, sums, scores, send, packed):

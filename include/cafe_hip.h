@@ -239,6 +239,22 @@ int cafe_backward_sgd_gid_dev(cafe_tables_t *t, const int32_t *d_fields, const i
  * (cafe_amd/sharded.py), and the owner updates straight from that buffer. */
 int cafe_backward_sgd_gid_strided_dev(cafe_tables_t *t, const int32_t *d_fields, const int32_t *d_que,
                                       const float *d_grad_out, int grad_row_stride, int n, float lr, cafe_stream_t stream);
+/* cafe_backward_update_dev for a shard: n lookups in arbitrary order (global id, field and routing word each), their rows
+ * row_stride floats apart in d_rows (a multiple of 4, > dim) with the lookup's gradient in columns [0, dim) and its SCORE at
+ * column dim, read in place -- the buffer the backward all-to-all delivers.  One batch_insert_val over the n ids in the
+ * order given, migration (local id = gid - id_offset[field]), SGD: run as one parallel insert with the device's verdict,
+ * the plan made beside cafe_forward_gid_dev, the update split by the library's rule, rejected steps issued again, like
+ * cafe_backward_update_dev with per_field == 0.  d_ins [n] out. */
+int cafe_backward_update_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_fields,
+                                 const int32_t *d_que, const float *d_rows, int row_stride, int n, float lr, int32_t *d_ins,
+                                 cafe_stream_t stream);
+/* The two permutations around the exchanges, one launch each.  pack: d_out[j] = [d_grad[order[j]] (dim floats) | score | 0 0 0]
+ * with score = d_norms[i] * scale / d_field_sums[i / batch] for i = order[j] (sk_embedding_bag.py:189 over the global
+ * batch: scale = global batch size), also written to d_scores[i] when d_scores != NULL.  unpack: d_out[order[j]] =
+ * d_back[j] (rows of dim floats).  d_order: int64 [n], a permutation. */
+int cafe_pack_rows_dev(const float *d_grad, const float *d_norms, const float *d_field_sums, float scale, int batch,
+                       const int64_t *d_order, int n, int dim, float *d_out, float *d_scores, cafe_stream_t stream);
+int cafe_unpack_rows_dev(const float *d_back, const int64_t *d_order, int n, int dim, float *d_out, cafe_stream_t stream);
 /* First half of cafe_scores_dev: d_norms[f*batch+i] = ||g_i||, d_field_sums[f] = sum_i ||g_i|| (fixed order), so that
  * ranks can all-reduce the sums before scaling (sk_embedding_bag.py:178-189 over the global batch). */
 int cafe_grad_norm_dev(cafe_tables_t *t, const float *d_grad_out, int batch, float *d_norms, float *d_field_sums,

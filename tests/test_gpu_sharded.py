@@ -112,6 +112,9 @@ def _rank(rank, world, port, q):
             if step % 2 == 0 and step + 1 < 8:
                 eng.prefetch(batches[step + 1])       # routed one step ahead on the exchange stream
         assert eng.host_syncs_in_step == 4
+        # every shard step ran as the fused owner step (cafe_backward_update_gid_dev): one parallel insert, none in order
+        c = eng.sketch.counters()
+        assert c["inorder_calls"] == 0 and c["parallel_calls"] == 8, c
         bad = om.states_equal(eng.sketch.state(), ref.state())
         assert not bad, bad
         q.put((rank, "ok"))
