@@ -10,11 +10,14 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5      # BASELINE.json north_star: embeddings within 1e-5 relative fp32 tolerance
 
 
+import os, sys  # noqa: E402
+sys.path.insert(0, os.path.dirname(__file__))
+from tol import close as _tol_close, ATOL_TABLE  # noqa: E402
+
+
 def _close(a, b, what):
-    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    scale = max(np.abs(b).max(), 1e-30)
-    err = np.abs(a - b).max() / scale
-    assert err <= RTOL, f"{what}: max rel err {err:.3e}"
+    """max-norm AND elementwise (tests/tol.py); small tables followed for tens to hundreds of steps: ATOL_TABLE"""
+    _tol_close(a, b, what, RTOL, ATOL_TABLE)
 
 
 from cpu_pipeline import CpuPipeline as _CpuPipeline  # noqa: E402

@@ -17,10 +17,12 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 
 
+from tol import close as _tol_close, ATOL_ROW  # noqa: E402
+
+
 def _close(a, b, what):
-    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
-    assert err <= RTOL, f"{what}: max rel err {err:.3e}"
+    """max-norm AND elementwise (tests/tol.py); two table steps are followed: ATOL_ROW"""
+    _tol_close(a, b, what, RTOL, ATOL_ROW)
 
 
 def test_cfg3_full_size_steps(oracle_mod):

@@ -63,7 +63,11 @@ def test_model_losses_match_cpu_twin(kind, dense_dim, per_field, oracle_mod):
         newly += int((ins != 0).sum())
         assert abs(loss.item() - loss_c.item()) <= RTOL * abs(loss_c.item()), f"{kind} step {step}: loss {loss.item()} vs {loss_c.item()}"
         assert np.array_equal(coll._buf["ins"].cpu().numpy().reshape(F, B), ins), f"{kind} step {step}: ins"
-    # decisions bit-exact; the accumulated scores come from gradients of two different matmul implementations
+    # decisions bit-exact; the accumulated scores, tables and head parameters are compared at 1e-4, not 1e-5: the twin's
+    # head runs on the CPU's GEMMs, the model's on rocBLAS, whose float32 results differ by ~1e-6 relative per product;
+    # the difference feeds back through SGD on the head at every step, so after these steps the two parameter sets have
+    # drifted by a few 1e-5 although every single step agrees to 1e-5 (the losses above are held to RTOL = 1e-5 per
+    # step).  The embedding path itself is held to 1e-5 with identical gradients in test_gpu_collection.py.
     a, b = coll.sketch.state(), cpu.sk.state()
     for k in ("mval", "mdic", "mflip", "lval", "ldic", "lt", "lflip", "fifo"):
         assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), f"{kind}: sketch {k}"

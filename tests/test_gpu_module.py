@@ -17,10 +17,14 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 
 
+import os, sys  # noqa: E402
+sys.path.insert(0, os.path.dirname(__file__))
+from tol import close as _tol_close, ATOL_TABLE  # noqa: E402
+
+
 def _close(a, b, what):
-    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
-    assert err <= RTOL, f"{what}: max rel err {err:.3e}"
+    """max-norm AND elementwise (tests/tol.py); small tables of the reference fixtures, several steps: ATOL_TABLE"""
+    _tol_close(a, b, what, RTOL, ATOL_TABLE)
 
 
 def test_module_fails_loudly_without_init():

@@ -1,7 +1,8 @@
 """cafe_amd.train end to end on the GPU: files in the reference's binary format -> model -> steps -> checkpoint
 (including the complete sketch) -> resume through the driver itself (it continues at the saved iteration, like the
 reference's ld_j, dlrm_s_pytorch.py:1512-1525).  A run resumed from its checkpoint must continue exactly like the
-uninterrupted run: same sketch decisions (bit-exact), tables and head within 1e-4 relative.  One field (60 ids) is
+uninterrupted run: same sketch decisions (bit-exact), tables, scores and head within 1e-5 relative (both runs are this
+package on the same GPU; they differ only in the order of the float atomics of rows that span several tiles).  One field (60 ids) is
 too small to be a sketch field at this compress rate and gets a plain table (dlrm_s_pytorch.py:323-343)."""
 import numpy as np
 import pytest
@@ -41,11 +42,11 @@ def test_files_checkpoint_resume(tmp_path, model_kind, dense, capsys):
         assert np.array_equal(np.asarray(sa[key]), np.asarray(sb[key])), key
     for key in ("num", "real_n", "clk", "flip", "batch_num"):
         assert sa[key] == sb[key], key
-    _close(sb["mcnt"], sa["mcnt"], "main scores", 1e-4)
-    _close(b.embedding.weight_high.cpu().numpy(), full.embedding.weight_high.cpu().numpy(), "hot table", 1e-4)
+    _close(sb["mcnt"], sa["mcnt"], "main scores")
+    _close(b.embedding.weight_high.cpu().numpy(), full.embedding.weight_high.cpu().numpy(), "hot table")
     for f in range(len(full.embedding.weight_hash)):
-        _close(b.embedding.weight_hash[f].cpu().numpy(), full.embedding.weight_hash[f].cpu().numpy(), f"cold {f}", 1e-4)
-    _close(b.plain[0].weight.detach().cpu().numpy(), full.plain[0].weight.detach().cpu().numpy(), "plain table", 1e-4)
+        _close(b.embedding.weight_hash[f].cpu().numpy(), full.embedding.weight_hash[f].cpu().numpy(), f"cold {f}")
+    _close(b.plain[0].weight.detach().cpu().numpy(), full.plain[0].weight.detach().cpu().numpy(), "plain table")
     for pa, pb in zip(full.head.parameters(), b.head.parameters()):
-        _close(pb.detach().cpu().numpy(), pa.detach().cpu().numpy(), "head", 1e-4)
+        _close(pb.detach().cpu().numpy(), pa.detach().cpu().numpy(), "head")
     assert (np.asarray(sa["mdic"]) != 0).sum() > 10            # ids did turn hot
