@@ -2367,6 +2367,9 @@ static int pick_cap(cafe_sketch *s, int n) {
     if (m->st.fallback) return 8192;
     if (big + big / 8 + 32 <= kCapSmall) return kCapSmall;
     if (big + big / 8 + 32 <= 2048) return 2048;
+    // (two owners per compute unit instead of one: cfg2 -22 % step time; a narrower margin, since a misfit only costs
+    // the reissue of that step with the largest owners)
+    if (big + big / 8 + 32 <= 4608) return 4608;
     return 8192;
 }
 
@@ -2413,6 +2416,7 @@ static int launch_plan(cafe_sketch *s, Geo &g, const IdSrc &ids, hipStream_t pre
                           (const Rec *)rec1, (const Rec *)rec2, (const Rec *)rech, rec1s, rec2s, rechs, w.pre_nmiss.as<uint32_t>())
     if (cap == kCapSmall) CAFE_PRESORT(kCapSmall);
     else if (cap == 2048) CAFE_PRESORT(2048);
+    else if (cap == 4608) CAFE_PRESORT(4608);
     else CAFE_PRESORT(8192);
 #undef CAFE_PRESORT
     CAFE_HIP_CHECK(hipGetLastError());
@@ -2497,13 +2501,16 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     // partitions are spread over more workgroups.  All of them are resident: at most two per compute unit of the <2048>
     // form (40 KB LDS), one of the <8192> form.
     const uint32_t mv = s->last_moves;
-    const int fix_grid = mv <= 256 ? kFixGrid : cap == 8192 ? 256 : 512;
+    const int fix_grid = mv <= 256 ? kFixGrid : cap > 2048 ? 256 : 512;
     if (cap == kCapSmall) {
         hipLaunchKernelGGL((k_round1<kCapSmall>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
         hipLaunchKernelGGL((k_fix<2048>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
     } else if (cap == 2048) {
         hipLaunchKernelGGL((k_round1<2048>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
         hipLaunchKernelGGL((k_fix<2048>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
+    } else if (cap == 4608) {
+        hipLaunchKernelGGL((k_round1<4608>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
+        hipLaunchKernelGGL((k_fix<8192>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
     } else {
         hipLaunchKernelGGL((k_round1<8192>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
         hipLaunchKernelGGL((k_fix<8192>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);

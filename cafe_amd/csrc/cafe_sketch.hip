@@ -379,6 +379,7 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     if (const char *e = getenv("CAFE_TARGET_ITEMS")) s->opt_target_items = std::max(16, atoi(e));   // tuning aids
     if (const char *e = getenv("CAFE_HOT_BYPASS")) s->opt_hot_bypass = atoi(e) ? 1 : 0;
     if (const char *e = getenv("CAFE_PRESORT")) s->opt_presort = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("CAFE_OWNER_CAP")) s->force_cap = atoi(e);
     s->n1 = (int)(lim * 0.9);           // sketch.cpp:51-52
     s->n2 = (int)(lim * 0.1);
     s->fifo_cap = (uint32_t)lim;
@@ -440,7 +441,7 @@ extern "C" int cafe_sketch_set_option(cafe_sketch_t *s, const char *name, int va
     else if (!strcmp(name, "presort")) s->opt_presort = value ? 1 : 0;
     else if (!strcmp(name, "ids_ready")) s->opt_ids_ready = value ? 1 : 0;
     else if (!strcmp(name, "split_update")) s->opt_split_update = value;
-    else if (!strcmp(name, "owner_cap")) s->force_cap = value == 1024 || value == 1536 ? 1536 : value == 2048 || value == 8192 ? value : 0;     // 1536 = kCapSmall (cafe_insert_par.hip)
+    else if (!strcmp(name, "owner_cap")) s->force_cap = value == 1024 || value == 1536 ? 1536 : value == 2048 || value == 4608 || value == 8192 ? value : 0;     // 1536 = kCapSmall (cafe_insert_par.hip)
     else if (!strcmp(name, "overlap")) s->opt_overlap = value;
     else if (!strcmp(name, "fuse_fields")) s->opt_fuse_fields = value ? 1 : 0;
     else if (!strcmp(name, "verify")) s->opt_verify = value ? 1 : 0;

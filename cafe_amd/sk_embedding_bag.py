@@ -164,7 +164,14 @@ class SKEmbeddingBag(nn.Module):
     @property
     def query_dic(self):
         """Hot mask of the last forward as a numpy bool array (sk_embedding_bag.py:130); copied on demand."""
+        if getattr(self, "_query_dic", None) is not None:
+            return self._query_dic
         return None if self._mask is None else self._mask.cpu().numpy()
+
+    @query_dic.setter
+    def query_dic(self, value):
+        # the reference assigns this attribute itself (sk_embedding_bag.py:130); code written against it may too
+        self._query_dic = value
 
     def _sketch(self):
         if self._sketch_h is None:
@@ -224,6 +231,7 @@ class SKEmbeddingBag(nn.Module):
                 _lib.check(self._L.cafe_forward_dev(self._sketch(), t, _p(ids), n, _p(gids), _p(que), _p(out), _stream()),
                            "cafe_forward_dev")
         self._ids, self._gids, self._que = ids, gids[:n], que[:n]
+        self._query_dic = None
         self.input_c = self._gids                 # sk_embedding_bag.py:106: the ids insert_grad will feed the sketch
         self._mask = self._que < 0
         return out

@@ -28,18 +28,22 @@ def _close(a, b, what):
 
 
 def test_module_fails_loudly_without_init():
-    import cafe_amd
-    from cafe_amd import _lib
-    from cafe_amd.sk_embedding_bag import SKEmbeddingBag
-
-    class NoLib:
-        pass
-    L = _lib.load()
-    if L.cafe_global_sketch():
-        pytest.skip("a global sketch already exists in this process")
-    e = SKEmbeddingBag(0, 100, NoLib(), torch.zeros(100, 16, device="cuda"), "cuda", 10, 16, 0, 3).cuda()
-    with pytest.raises(_lib.CafeError):
-        e(torch.arange(4), torch.arange(4))
+    """A module used before lib.init(...) must raise, not fall back to anything.  Run in a process of its own: whether a
+    global sketch exists is process state (an earlier test of the session may have called init)."""
+    import subprocess
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from cafe_amd import _lib\n"
+        "from cafe_amd.sk_embedding_bag import SKEmbeddingBag\n"
+        "class NoLib: pass\n"
+        "assert not _lib.load().cafe_global_sketch()\n"
+        "e = SKEmbeddingBag(0, 100, NoLib(), torch.zeros(100, 16, device='cuda'), 'cuda', 10, 16, 0, 3).cuda()\n"
+        "try:\n"
+        "    e(torch.arange(4), torch.arange(4))\n"
+        "except _lib.CafeError as ex:\n"
+        "    print('RAISED', ex)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert "RAISED" in r.stdout and "lib.init" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("name", module_golden_names())
