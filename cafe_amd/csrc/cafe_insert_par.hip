@@ -1604,26 +1604,38 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
             LruR b;
             load_lru(b, &A.lt[b0 + (int)bl]);
             sync_flip(b, gflip);
+            // the end of the bucket's items, found 64 at a time (the walk below then needs no key per item)
+            int end = s;
+            for (;;) {
+                const int idx = end + lane;
+                const unsigned long long m = __ballot(idx < nmiss && L.s.sg[idx] == bl);
+                const int rr = (~m) ? __builtin_ctzll(~m) : 64;
+                end += rr;
+                if (rr < 64) break;
+            }
             int e = s;
-            while (e < nmiss && L.s.sg[e] == bl) {
+            while (e < end) {
+                // id, position and score of the item in one LDS round trip
                 const uint32_t x = L.s.px[e];
+                const uint32_t pos = L.s.stm[e];
+                const float c = L.s.pc[e];
                 const int f = lru_find(b, x);
                 if (f >= 0) {
                     const int idx = e + lane;
-                    const bool same = idx < nmiss && L.s.sg[idx] == bl && L.s.px[idx] == x;
+                    const bool same = idx < end && L.s.px[idx] == x;
                     const unsigned long long m = __ballot(same);
                     const int r = (~m) ? __builtin_ctzll(~m) : 64;            // length of the run starting at e (>= 1)
-                    const float c = lane < r ? L.s.pc[idx] : 0.0f;
+                    const float cl = lane < r ? L.s.pc[idx] : 0.0f;
                     float acc = sel4f(b.c0, b.c1, b.c2, b.c3, f), mine = 0.0f;
                     for (int j = 0; j < r; ++j) {
-                        acc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), j));
+                        acc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl), j));
                         mine = lane == j ? acc : mine;
                     }
                     const unsigned long long km = __ballot(lane < r && mine >= thr);
                     const int k = km ? __builtin_ctzll(km) : r;                // probes before the first one that reaches thr
                     if (k > 0) {
                         const float upto = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), k - 1));
-                        const int32_t tlast = A.st->clk + 1 + (int32_t)L.s.stm[e + k - 1];
+                        const int32_t tlast = ctx.clk0 + 1 + (int32_t)L.s.stm[e + k - 1];
                         CAFE_SET4(b.c0, b.c1, b.c2, b.c3, f, upto);
                         CAFE_SET4(b.t0, b.t1, b.t2, b.t3, f, tlast);
                         if (lane < k) L.s.po[e + lane] = 0;
@@ -1631,8 +1643,6 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
                         continue;
                     }
                 }
-                const uint32_t pos = L.s.stm[e];
-                const float c = L.s.pc[e];
                 ctx.pos = pos; ctx.flags = 0;
                 MoveReq mv;
                 int got;
@@ -2502,19 +2512,14 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     // form (40 KB LDS), one of the <8192> form.
     const uint32_t mv = s->last_moves;
     const int fix_grid = mv <= 256 ? kFixGrid : cap > 2048 ? 256 : 512;
-    if (cap == kCapSmall) {
-        hipLaunchKernelGGL((k_round1<kCapSmall>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
-        hipLaunchKernelGGL((k_fix<2048>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
-    } else if (cap == 2048) {
-        hipLaunchKernelGGL((k_round1<2048>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
-        hipLaunchKernelGGL((k_fix<2048>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
-    } else if (cap == 4608) {
-        hipLaunchKernelGGL((k_round1<4608>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
-        hipLaunchKernelGGL((k_fix<8192>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
-    } else {
-        hipLaunchKernelGGL((k_round1<8192>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc);
-        hipLaunchKernelGGL((k_fix<8192>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
-    }
+#define CAFE_R1(C) hipLaunchKernelGGL((k_round1<C>), dim3(grid1), dim3(kThreads), 0, st, g, MA, LA, HA, sc)
+    if (cap == kCapSmall) CAFE_R1(kCapSmall);
+    else if (cap == 2048) CAFE_R1(2048);
+    else if (cap == 4608) CAFE_R1(4608);
+    else CAFE_R1(8192);
+#undef CAFE_R1
+    if (cap <= 2048) hipLaunchKernelGGL((k_fix<2048>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
+    else hipLaunchKernelGGL((k_fix<8192>), dim3(fix_grid), dim3(kThreads), 0, st, g, MA, LA, sc);
     // ---- finish ----
     const int nb = (n + kScanBlock - 1) / kScanBlock;
     uint8_t *flags = w.flags.as<uint8_t>();

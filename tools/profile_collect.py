@@ -11,7 +11,7 @@
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 
@@ -33,7 +33,7 @@ def pmc(d, counter):
             per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     res = {}
     for k, v in per.items():
-        tail = v[len(v) // 2:]                     # steady state: the last half of the launches
+        tail = v[-100:] if len(v) > 200 else v[len(v) // 2:]         # steady state: the last 100 launches (behind the preheat)
         res[k] = (sum(tail) / len(tail), len(v))
     return res
 
@@ -64,7 +64,7 @@ F, B, D = 26, 8192, 128
 alg = {"k_forward": F * B * (56 + 8 * D), "k_bwd_segments": F * B * 12 * D, "k_grad_norm": F * B * (4 * D + 4)}
 tj = {"workload": "cfg3/b8192",
       "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/profile_round.sh {tag}) of `bench.py --steps 6 "
-                "--warmup 2 --preheat 30`, per-launch mean of the last half of the launches; FETCH_SIZE is in KiB and doubled (gfx950 "
+                "--warmup 2 --preheat 1000` (no forced form of the update), per-launch mean of the last 100 launches of each kernel; FETCH_SIZE is in KiB and doubled (gfx950 "
                 "tallies 128-B requests at 64 B for 16-B-per-lane reads, MI355X_MICROARCH.md HBM section; calibration: k_grad_norm reads "
                 "exactly 109.05 MB), WRITE_SIZE in KiB taken as is (calibration: k_forward writes 109.05 MB + 1.7 MB)"}
 for k in ("k_forward", "k_bwd_segments", "k_grad_norm"):
