@@ -109,6 +109,7 @@ struct ParWorkspace {
     DevBuf cm, colpref, tot, off, plan, items, ev, evres, miss, outm, outl, stage_m, stage_l, stage_tot, prevcnt;
     DevBuf hkey, hrun, hfin;
     DevBuf items_sorted, pre_nmiss;      // k_presort: the partitions' records in owner order, misses per LRU partition
+    DevBuf r1_order;                     // k_offsets: the round-1 owners by estimated cost, heaviest first
     DevBuf ldirty, myev, mycnt;
     DevBuf flags, agg, ranks, gotlist;
     void *evres_seen = nullptr;
@@ -316,11 +317,13 @@ __global__ void __launch_bounds__(kPlanThreads) k_assign(Geo g, const MainBucket
 // finishes last turns the bin totals into partition offsets, zeroes the control block and applies the per-call scalars
 // of sketch.cpp:282-289 (the flip decision is the host's: it depends on the call count only).
 constexpr int kOffBins = 32, kOffParts = kThreads / kOffBins;
+constexpr int kCostClasses = 256;
 __global__ void __launch_bounds__(kThreads) k_offsets(Geo g, const uint16_t *__restrict__ cm, uint32_t *__restrict__ colpref,
                                                       uint32_t *__restrict__ tot, uint32_t *__restrict__ off, Ctl *ctl,
-                                                      uint32_t *__restrict__ evcnt, DevState *st) {
+                                                      uint32_t *__restrict__ evcnt, DevState *st, uint32_t *__restrict__ order) {
     CAFE_KWIN(1);
     __shared__ uint32_t sh[kThreads];
+    __shared__ uint32_t chist[kCostClasses];
     __shared__ uint32_t excl[kMaxPlanBins + 1];
     __shared__ uint32_t last;
     const int tid = threadIdx.x;
@@ -443,6 +446,40 @@ __global__ void __launch_bounds__(kThreads) k_offsets(Geo g, const uint16_t *__r
             off[off_lru0(g) + g.P2] = base2 - base1;
             off[off_hot0(g) + g.PH] = total - base2;
         }
+    }
+    // The round-1 owners by estimated cost, heaviest first (a counting sort over cost classes; the order inside a class is
+    // whatever the atomics give: it decides nothing but which workgroup takes which partition).  Used when the owners'
+    // LDS lets only some of them be resident at once (k_round1 with the large capacities): a hot partition with a field's
+    // most frequent id (thousands of dependent adds) and the LRU partitions (tens of dependent transitions per bucket)
+    // then start first and the many light partitions fill in behind them.
+    if (order && !(g.hot && g.hot_table)) {
+        const int nhot = g.hot ? g.PH : 0, n1 = nhot + g.P2 + g.P1;
+        const int l1 = bin_lru0(g), l2 = bin_hot0(g);
+        auto cost_class = [&](int k) -> int {
+            uint32_t c;
+            if (k < nhot) c = 512u + 2u * (excl[l2 + k + 1] - excl[l2 + k]);
+            else if (k < nhot + g.P2) c = 512u + 48u * (excl[l1 + (k - nhot) + 1] - excl[l1 + (k - nhot)]) / (uint32_t)max(1, g.bpp2);
+            else { const int q = k - nhot - g.P2; c = 512u + 32u * (excl[2 * q + 1] - excl[2 * q]) / (uint32_t)max(1, g.bpp1); }
+            return kCostClasses - 1 - (int)min(c >> 6, (uint32_t)(kCostClasses - 1));       // heavier = lower class
+        };
+        for (int i = tid; i < kCostClasses; i += kThreads) chist[i] = 0;
+        __syncthreads();
+        for (int k = tid; k < n1; k += kThreads) atomicAdd(&chist[cost_class(k)], 1u);
+        __syncthreads();
+        if (tid < 64) {
+            // exclusive scan over the classes by one wave
+            constexpr int per = kCostClasses / 64;
+            uint32_t v[per], sum = 0;
+#pragma unroll
+            for (int u = 0; u < per; ++u) { v[u] = chist[tid * per + u]; sum += v[u]; }
+            uint32_t inc = sum;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if (tid >= d) inc += x; }
+            uint32_t run = inc - sum;
+#pragma unroll
+            for (int u = 0; u < per; ++u) { chist[tid * per + u] = run; run += v[u]; }
+        }
+        __syncthreads();
+        for (int k = tid; k < n1; k += kThreads) order[atomicAdd(&chist[cost_class(k)], 1u)] = (uint32_t)k;
     }
     CAFE_STAMP(3, 3);
     // control block and move counters start at zero; the LRU clock placeholder clock0 + 1 + position must stay positive
@@ -1688,6 +1725,7 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
 // round 1: hot partitions, LRU partitions and main partitions (class C) in one launch
 // ------------------------------------------------------------------------------------------------
 struct HotArgs {
+    const uint32_t *order;      // the owners by estimated cost, heaviest first (k_offsets), or nullptr: in grid order
     const Rec *rechs;           // the hot list's partitions in owner order (k_presort)
     const Rec *rech;
     unsigned long long *hkey;
@@ -1706,7 +1744,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(C
     // control word reports a limit -- one memory round trip less in every owner)
     CAFE_STAMP_VAL(0, 7, 0ull);
     CAFE_STAMP(0, 0);
-    int b = blockIdx.x;
+    int b = HA.order ? (int)HA.order[blockIdx.x] : (int)blockIdx.x;
     const int nhot = !g.hot ? 0 : g.hot_table ? (g.PH + kWaves - 1) / kWaves : g.PH;
     if (b < nhot) {
         if (g.hot_table) {
@@ -2319,7 +2357,7 @@ static int ensure_ws(cafe_sketch *s, int n, Geo &g) {
     const size_t mat = (size_t)g.nchunks * g.nbins;
     if (w.ctl.reserve(4 * (kCtlWords + 2 * (size_t)kMaxParts + 16)) || w.cm.reserve(2 * mat + 16) || w.colpref.reserve(4 * mat + 16) ||
         w.tot.reserve(4 * (size_t)g.nbins + 16) || w.off.reserve(4 * ((size_t)g.nbins + 8)) || w.plan.reserve(8 * N + 16) ||
-        w.items.reserve(3 * sizeof(Rec) * N + 64) || w.items_sorted.reserve(3 * sizeof(Rec) * N + 64) || w.pre_nmiss.reserve(4 * (size_t)kMaxParts + 16) || w.hkey.reserve(8 * N + 16) || w.hrun.reserve(4 * N + 16) || w.hfin.reserve(8 * N + 16) ||
+        w.items.reserve(3 * sizeof(Rec) * N + 64) || w.items_sorted.reserve(3 * sizeof(Rec) * N + 64) || w.pre_nmiss.reserve(4 * (size_t)kMaxParts + 16) || w.r1_order.reserve(4 * 3 * (size_t)kMaxParts + 16) || w.hkey.reserve(8 * N + 16) || w.hrun.reserve(4 * N + 16) || w.hfin.reserve(8 * N + 16) ||
         w.ev.reserve(2 * sizeof(MoveEv) * (size_t)g.P1 * g.evs) || w.evres.reserve(sizeof(EvRes) * N + 64) || w.miss.reserve(N + 16) ||
         w.outm.reserve(N + 16) || w.outl.reserve(N + 16) ||
         w.stage_m.reserve(sizeof(MainBucket) * (N + (size_t)g.P1 * g.evs)) || w.stage_l.reserve(sizeof(LruBucket) * N + 128) ||
@@ -2403,7 +2441,7 @@ static int launch_plan(cafe_sketch *s, Geo &g, const IdSrc &ids, hipStream_t pre
     }
     hipLaunchKernelGGL(k_assign, dim3(g.nchunks), dim3(kPlanThreads), plan_lds, pre, g, s->d_main, ids, w.cm.as<uint16_t>(), planA, planB);
     hipLaunchKernelGGL(k_offsets, dim3((g.nbins + kOffBins - 1) / kOffBins), dim3(kThreads), 0, pre, g, w.cm.as<uint16_t>(),
-                       w.colpref.as<uint32_t>(), w.tot.as<uint32_t>(), off, ctl, evcnt, s->d_state);
+                       w.colpref.as<uint32_t>(), w.tot.as<uint32_t>(), off, ctl, evcnt, s->d_state, w.r1_order.as<uint32_t>());
     // (the plan's completion event rides on its last kernel: no marker packet)
     // The owner-order pass pays where the insert's chain is the step's critical path.  Where the update runs split (its
     // gradient pass sits beside the chain and the row updates wait for IT), a shorter chain buys nothing and one more
@@ -2504,6 +2542,8 @@ int par_insert(cafe_sketch *s, const int32_t *d_ids, const float *d_vals, const 
     LA.pre_nmiss = w.pre_nmiss.as<uint32_t>();
     HA.rech = rech; HA.hkey = w.hkey.as<unsigned long long>(); HA.hrun = w.hrun.as<float>(); HA.hfin = w.hfin.as<int2>();
     const int cap = pick_cap(s, n);
+    // (with the small owners every partition's workgroup is resident at once: grid order, no indirection)
+    HA.order = (cap > 2048 && !(g.hot && g.hot_table) && s->opt_r1_order) ? w.r1_order.as<uint32_t>() : nullptr;
     if (s->ev_chain[0]) (void)hipEventRecord(s->ev_chain[0], st);
     const int grid1 = (!g.hot ? 0 : g.hot_table ? (g.PH + kWaves - 1) / kWaves : g.PH) + g.P2 + g.P1;
     // The fix-point kernel is persistent (grid barrier between half-rounds): a quiet stream has a few tens of moves per
@@ -2557,7 +2597,7 @@ void par_free(cafe_sketch *s) {
     ParWorkspace &w = *s->par;
     DevBuf *all[] = {&w.ctl, &w.cm, &w.colpref, &w.tot, &w.off, &w.plan, &w.items, &w.ev, &w.evres, &w.miss, &w.outm, &w.outl,
                      &w.stage_m, &w.stage_l, &w.stage_tot, &w.prevcnt, &w.ldirty, &w.myev, &w.mycnt, &w.flags, &w.agg, &w.ranks,
-                     &w.gotlist, &w.hkey, &w.hrun, &w.hfin, &w.items_sorted, &w.pre_nmiss};
+                     &w.gotlist, &w.hkey, &w.hrun, &w.hfin, &w.items_sorted, &w.pre_nmiss, &w.r1_order};
     for (DevBuf *b : all) b->release();
     delete s->par;
     s->par = nullptr;

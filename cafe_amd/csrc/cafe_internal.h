@@ -53,6 +53,7 @@ struct cafe_sketch {
     // options / counters
     int opt_serial = 0, opt_max_rounds = 6, opt_target_items = 448, opt_hot_bypass = 1, opt_hot_table = 0, opt_move_cap = 1 << 20, opt_ids_ready = 0;
     int64_t inner_reset_rejects = 0;     // fused steps the device rejected because sketch.cpp:291 fired at an inner field boundary
+    int opt_r1_order = 1;               // round-1 owners start heaviest first when they cannot all be resident (tuning aid: CAFE_R1_ORDER)
     int force_cap = 0;                  // option "owner_cap": items an owner workgroup can hold (0 = chosen per call)
     int force_cap_once = 0;             // ... for the call being issued (a step issued again after a workspace limit)
     int score_seg = 0;                  // > 0: vals are norms, scaled per segment of score_seg ids (ScoreSrc)

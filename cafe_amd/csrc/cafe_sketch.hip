@@ -380,6 +380,7 @@ extern "C" int cafe_sketch_create(cafe_sketch_t **out, int lim, int threshold, i
     if (const char *e = getenv("CAFE_HOT_BYPASS")) s->opt_hot_bypass = atoi(e) ? 1 : 0;
     if (const char *e = getenv("CAFE_PRESORT")) s->opt_presort = atoi(e) ? 1 : 0;
     if (const char *e = getenv("CAFE_OWNER_CAP")) s->force_cap = atoi(e);
+    if (const char *e = getenv("CAFE_R1_ORDER")) s->opt_r1_order = atoi(e) ? 1 : 0;
     s->n1 = (int)(lim * 0.9);           // sketch.cpp:51-52
     s->n2 = (int)(lim * 0.1);
     s->fifo_cap = (uint32_t)lim;

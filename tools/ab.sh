@@ -8,7 +8,7 @@ args=()
 run() {
   # arguments of the form NAME=VALUE go to the environment of that run
   local envs=() rest=()
-  for a in "${args[@]}"; do if [[ "$a" =~ ^[A-Z_]+=.*$ ]]; then envs+=("$a"); else rest+=("$a"); fi; done
+  for a in "${args[@]}"; do if [[ "$a" =~ ^[A-Z_0-9]+=.*$ ]]; then envs+=("$a"); else rest+=("$a"); fi; done
   env "${envs[@]}" timeout -k 10 300 python -u bench.py --no-cpu-baseline "${rest[@]}" > gpurun_out/ab_${tag}_$i.json 2> gpurun_out/ab_${tag}_$i.err || { tail -5 gpurun_out/ab_${tag}_$i.err; exit 1; }
   python - <<PY
 import json
