@@ -25,6 +25,23 @@ def find(d, pat):
 
 shutil.copy(find(f"{tag}_stats", "*kernel_stats.csv"), os.path.join(out, f"{tag}_bench_cfg3_kernel_stats.csv"))
 
+# The stats above average over the whole run, the 1000 untimed steps that build the sketch's hot set included (their churn
+# shows in k_fix and in the one-kernel form of the update).  The same trace, last 300 launches of every kernel only:
+trace = glob.glob(os.path.join(root, "gpurun_out", f"{tag}_stats", "**", "*kernel_trace.csv"), recursive=True)
+if trace:
+    per = defaultdict(list)
+    for r in csv.DictReader(open(trace[0])):
+        per[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    with open(os.path.join(out, f"{tag}_bench_cfg3_kernel_stats_steady.csv"), "w") as f:
+        f.write("Name,Calls,LastCalls,AverageNs,MinNs,MaxNs\n")
+        rows = []
+        for k, v in per.items():
+            v.sort()
+            d = [x[1] for x in v[-300:]]
+            rows.append((sum(d), k, len(v), len(d), sum(d) / len(d), min(d), max(d)))
+        for _, k, n, m, avg, lo, hi in sorted(rows, reverse=True):
+            f.write(f"\"{k}\",{n},{m},{avg:.0f},{lo},{hi}\n")
+
 
 def pmc(d, counter):
     per = defaultdict(list)
@@ -89,3 +106,17 @@ for k in ("k_forward", "k_bwd_segments", "k_grad_norm"):
         tj[k]["kernels"] = parts
 json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(tj, indent=1))
+
+
+# LDS bank conflicts (tools/profile_lds.sh): a pass of its own, summarised when its output is there
+lds = glob.glob(os.path.join(root, "gpurun_out", f"{tag}_lds", "**", "*counter_collection.csv"), recursive=True)
+if lds:
+    act, conf = pmc(f"{tag}_lds", "SQ_LDS_IDX_ACTIVE"), pmc(f"{tag}_lds", "SQ_LDS_BANK_CONFLICT")
+    with open(os.path.join(out, f"{tag}_pmc_lds_summary.txt"), "w") as f:
+        f.write(f"rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE (tools/profile_lds.sh {tag}) of `bench.py --steps 6 --warmup 2 --preheat 1000`;\n"
+                "per-launch mean of the last 100 launches of each kernel; conflict share = extra cycles / all LDS-array cycles\n\n")
+        f.write(f"{'kernel':50s} {'LDS_IDX_ACTIVE':>17s} {'BANK_CONFLICT':>14s} {'share':>7s}  calls\n")
+        for k, (a, n) in sorted(act.items(), key=lambda kv: -kv[1][0]):
+            c = conf.get(k, (0.0, 0))[0]
+            if a > 0:
+                f.write(f"{k[:46]:50s} {a:17.0f} {c:14.0f} {100.0 * c / a:6.1f}%  {n}\n")
