@@ -342,3 +342,52 @@ def test_many_live_handles_do_not_starve_a_split_update_step(oracle_mod):
         assert int((sk.query(np.arange(1, 65, dtype=np.int64) + i) != 0).sum()) == 64
     for sk in others:
         sk.close()
+
+
+def test_backward_for_an_earlier_forward_under_a_split_update(oracle_mod):
+    """the update's partition workspaces are one set per tables handle, and a forward queues its partition
+    passes on the library's third stream.  forward A, forward B (an evaluation batch between forward and backward), then
+    the backward of A: A's own partition passes run on another stream and must wait for B's passes still in flight
+    instead of sharing the counters with them.  Every step is compared with the oracle (B changes no state)."""
+    from cafe_amd.collection import CafeEmbeddingCollection
+    F, dim, thr, B, hotn = 4, 16, 2, 8192, 1200
+    counts = [40000, 9000, 70000, 3000]
+    hash_sizes = [211, 37, 499, 13]
+    coll = CafeEmbeddingCollection(counts, dim, hotn, hash_sizes, threshold=thr, adjust_thres=1, alpha=1.0000005, seed=6)
+    coll.sketch.set_option("split_update", 2)
+    cpu = _CpuPipeline(oracle_mod, coll, thr, 1, 1.0000005)
+    rng = np.random.default_rng(31)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+
+    def draw(step):
+        ids = np.stack([(rng.zipf(1.15, size=B) - 1 + step * 11) % c for c in counts]).astype(np.int64)
+        ids[0] = np.maximum(ids[0], 1)
+        return ids
+
+    out_a = torch.empty(F, B, dim, device="cuda")
+    out_b = torch.empty(F, B, dim, device="cuda")
+    for step in range(8):
+        ids_a, ids_b = draw(step), draw(step + 100)
+        d_a, d_b = torch.from_numpy(ids_a).cuda(), torch.from_numpy(ids_b).cuda()
+        grad = torch.randn(F, B, dim, device="cuda", generator=gen)
+        coll.forward(d_a, out=out_a)
+        kept = (coll._ids, coll._B, coll._buf["gids"], coll._buf["que"], coll._which)
+        want_a = cpu.forward(ids_a)
+        que_a = np.stack(cpu.que)
+        coll.forward(d_b, out=out_b)                 # its partition passes are queued behind it
+        want_b = cpu.forward(ids_b)
+        _close(out_b.cpu().numpy(), want_b, f"step {step} forward B")
+        # back to A: ids, routing arrays and the oracle's routing of A
+        coll._ids, coll._B, coll._buf["gids"], coll._buf["que"], coll._which = kept
+        cpu.forward(ids_a)
+        assert np.array_equal(coll._buf["que"].cpu().numpy().reshape(F, B), que_a), f"step {step}: routing of A"
+        _close(out_a.cpu().numpy(), want_a, f"step {step} forward A")
+        scores, ins = coll.backward_update(grad, 0.05, per_field_calls=True)
+        sc = scores.cpu().numpy().reshape(F, B)
+        ins_want = cpu.backward_update(ids_a, grad.cpu().numpy(), sc, 0.05, True)
+        assert np.array_equal(ins.cpu().numpy().reshape(F, B), ins_want), f"step {step}: ins differs"
+    bad = oracle_mod.states_equal(coll.sketch.state(), cpu.sk.state())
+    assert not bad, bad[:3]
+    _close(coll.weight_high.cpu().numpy(), cpu.w_hot, "hot table")
+    for f in range(F):
+        _close(coll.weight_hash[f].cpu().numpy(), cpu.w_cold[f], f"cold table {f}")
