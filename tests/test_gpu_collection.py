@@ -1,6 +1,7 @@
 """GPU parity of the whole hot path (forward gather, scores, sketch insert, migration, backward+SGD)
 against the CPU oracle: sketch decisions bit-exact, gathered rows bit-exact (pure copies), scores and
 updated tables within 1e-5 relative (float32 sums in a different order)."""
+import time
 import numpy as np
 import pytest
 import torch
@@ -203,8 +204,10 @@ def _run_steps(coll, cpu, oracle_mod, batches, grads, lr=0.05, check_tables=True
             _close(out.cpu().numpy(), want, f"step {step} forward")
             if step + 1 < len(batches):
                 coll.hint_next(d_batches[step + 1], outs[(step + 1) % 2])
+        t_dev = time.perf_counter()
         scores, ins = coll.backward_update(grad, lr, per_field_calls=True)
         sc = scores.cpu().numpy().reshape(F, B)
+        _run_steps.slowest = max(getattr(_run_steps, "slowest", 0.0), time.perf_counter() - t_dev)
         ins_want = cpu.backward_update(ids, grad.cpu().numpy(), sc, lr, True)
         assert np.array_equal(ins.cpu().numpy().reshape(F, B), ins_want), f"step {step}: ins differs"
         deltas.append(cpu.sk.state()["real_n"] - before)
@@ -304,7 +307,13 @@ def test_fused_steps_that_the_device_rejects_stay_exact(option, value, reason, h
         g = torch.randn(F, B, dim, device="cuda", generator=gen)
         g[:, ::3] *= 8.0                      # large scores: evicted LRU entries qualify for a move (sketch.cpp:193-195)
         batches.append(ids); grads.append(g)
-    _run_steps(coll, cpu, oracle_mod, batches, grads, hint=hint)
+    _run_steps(coll, cpu, oracle_mod, batches[:2], grads[:2], hint=hint)        # workspaces allocated, kernels loaded
+    _run_steps.slowest = 0.0
+    _run_steps(coll, cpu, oracle_mod, batches[2:], grads[2:], hint=hint)
+    # a limit hit in a later round must not leave the persistent fix-point kernel waiting at a grid barrier that
+    # some workgroups have left (a stall of 10 s and more before the bounded wait gave up): every update, its reissues
+    # included, comes back promptly
+    assert _run_steps.slowest < 2.0, f"slowest update took {_run_steps.slowest:.2f} s"
     c = coll.sketch.counters()
     if hint:
         used, dropped = coll.hint_stats()
