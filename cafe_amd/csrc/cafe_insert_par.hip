@@ -61,6 +61,8 @@ constexpr int kCapEvL = 1024;         // moves one LRU partition can emit per ro
 constexpr int kMaxRounds = 16;
 constexpr int kHeavySeg = 4;          // a bucket with at least this many items in the batch is replayed by a whole wave
 constexpr int kLruHeavy = 32;         // an LRU bucket with at least this many items in the batch is replayed by a whole wave
+constexpr int kLruQuad = 8;           // ... with at least this many, and no long runs of one id, by four lanes (one per slot)
+constexpr int kQuadTag = 0x40000000;  // heavy-list entry: replayed by a lane quad, not by a wave
 constexpr int kMaxHeavy = 64;         // heavy buckets one partition can hand to its waves (more: replayed by single lanes)
 constexpr int kScanBlock = 1024;
 constexpr int kDigitBits = 10, kDigits = 1 << kDigitBits;
@@ -1593,9 +1595,18 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
         if (s != 0 && L.s.sg[s - 1] == bl) continue;
         // a bucket with many items (an id that is frequent but not hot yet: it lives here until its score reaches the
         // threshold) is left to phase B, where a whole wave walks it
-        if (s + kLruHeavy <= nmiss && L.s.sg[s + kLruHeavy - 1] == bl) {
+        // Which replay: a bucket whose items are mostly runs of ONE id (sampled at three places) goes to a wave, which
+        // compresses runs; a bucket of many different ids (a small sketch under a large batch: every LRU bucket of cfg2
+        // and cfg5 replays tens to hundreds of misses) goes to a lane quad, one lane per slot, whose step per item is a
+        // dozen dependent instructions instead of the select chains of the one-lane form.
+        if (s + kLruQuad <= nmiss && L.s.sg[s + kLruQuad - 1] == bl) {
+            bool runs = false;
+            if (s + kLruHeavy <= nmiss && L.s.sg[s + kLruHeavy - 1] == bl) {
+                const int same = (L.s.px[s] == L.s.px[s + 1]) + (L.s.px[s + 15] == L.s.px[s + 16]) + (L.s.px[s + 30] == L.s.px[s + 31]);
+                runs = same >= 2;
+            }
             const int at = atomicAdd(n_hv, 1);
-            if (at < kMaxHeavy) { heavy[at] = s; continue; }
+            if (at < kMaxHeavy) { heavy[at] = runs ? s : (s | kQuadTag); continue; }
         }
         LruR b;
         load_lru(b, &A.lt[b0 + (int)bl]);
@@ -1628,14 +1639,100 @@ __device__ inline void lru_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_hv, in
         store_lru(&stage[s], b, b0 + (int)bl);
     }
     __syncthreads();
-    // Phase B: heavy buckets, one per wave at a time; all 64 lanes carry the same bucket copy.  A run of probes of one id
-    // that sits in the bucket and stays below the threshold only moves its score (ordered float sum: one readlane + add
-    // per item) and its timestamp; the first probe that reaches the threshold, and every miss, takes the one-item step
-    // (sketch.cpp:165-209), executed uniformly with lane 0 writing.
+    // Phase Q: buckets of many different ids, one per lane quad (16 per wave, 64 per workgroup at a time).  Lane j of
+    // the quad holds slot j of the bucket in registers.  Per item (sketch.cpp:165-209): the hit slot from a ballot of
+    // val == id, the victim (first slot with the smallest timestamp) from the four timestamps broadcast inside the quad by
+    // DPP, and the lane of the target slot alone applies lru_hit / lru_evict + lru_place to its slot -- no select chains
+    // over slots.  The next item's words are requested while the current one is applied.
+    {
+        const int lane = tid & 63, wave = tid >> 6, sub = lane & 3, qshift = lane & ~3;
+        const int nh = min(*n_hv, kMaxHeavy);
+        const int hv = lane < nh ? heavy[lane] : 0;
+        const unsigned long long qall = __ballot(lane < nh && (hv & kQuadTag));
+        for (int base = 0; base < __popcll(qall); base += 16 * kWaves) {
+            unsigned long long qm = qall;
+            const int gq = base + wave * 16 + (lane >> 2);
+            for (int i = 0; i < gq && qm; ++i) qm &= qm - 1;          // the gq-th quad entry of the list
+            if (!qm) continue;
+            const int s = heavy[__builtin_ctzll(qm)] & ~kQuadTag;
+            const uint32_t bl = L.s.sg[s];
+            const int32_t *src = reinterpret_cast<const int32_t *>(&A.lt[b0 + (int)bl]);
+            int32_t v = src[sub], d = src[4 + sub], t = src[12 + sub];
+            float c = __int_as_float(src[8 + sub]);
+            if ((uint32_t)src[16] != gflip) c = decay_once(c);           // sync_flip
+            int e = s;
+            uint32_t x = L.s.px[e], pos = L.s.stm[e];
+            float ci = L.s.pc[e];
+            bool act = true;
+            while (act) {
+                const int en = min(e + 1, CAP - 1);
+                const uint32_t sgn = L.s.sg[en], xn = L.s.px[en], posn = L.s.stm[en];
+                const float cn = L.s.pc[en];
+                const uint32_t hn = (uint32_t)(__ballot((uint32_t)v == x) >> qshift) & 0xFu;
+                const int32_t t0 = __builtin_amdgcn_update_dpp(0, t, 0x00, 0xF, 0xF, false), t1 = __builtin_amdgcn_update_dpp(0, t, 0x55, 0xF, 0xF, false),
+                              t2 = __builtin_amdgcn_update_dpp(0, t, 0xAA, 0xF, 0xF, false), t3 = __builtin_amdgcn_update_dpp(0, t, 0xFF, 0xF, 0xF, false);
+                int victim = -1, t_min = 1000000000;                    // lru_find: first slot with the smallest timestamp
+                if (t_min > t0) { t_min = t0; victim = 0; }
+                if (t_min > t1) { t_min = t1; victim = 1; }
+                if (t_min > t2) { t_min = t2; victim = 2; }
+                if (t_min > t3) { t_min = t3; victim = 3; }
+                if (victim < 0) victim = 0;
+                const bool hit = hn != 0u;
+                const int target = hit ? __builtin_ctz(hn) : victim;
+                // both transitions of the slot, computed by every lane on its own slot without a branch; the target lane
+                // keeps the one that applies (lru_hit / lru_evict + lru_place, cafe_core.h)
+                const bool mine = sub == target;
+                const int32_t tk = ctx.clk0 + 1 + (int32_t)pos;          // LruCtx::tick
+                const int32_t pl = (int32_t)(kSur | pos);                // LruCtx::pop
+                const float now = c + ci;
+                const bool reach = now >= thr;
+                const bool h_pop = reach && ctx.full && d == 0;
+                const int32_t h_dic = h_pop ? pl : d;
+                const bool m_ev = d != 0 || c >= 5.0f;
+                const bool m_one = 1.0f >= thr;
+                const bool m_pop = m_one && ctx.full;
+                const uint8_t fl = hit ? (uint8_t)(((reach && now - ci < thr) ? oCross : 0) | (h_pop ? (oPop | oGot) : 0) | (reach ? oEv : 0))
+                                       : (uint8_t)(((m_one && 1.0f - ci < thr) ? oCross : 0) | (m_pop ? (oPop | oGot) : 0) | (m_ev ? oEv : 0));
+                const int mk = hit ? (reach ? 1 : 0) : (m_ev ? 2 : 0);
+                const uint32_t mx = (uint32_t)v;
+                const float mc = hit ? now : c;
+                const int32_t md = hit ? h_dic : d;
+                const int32_t nv = hit ? (reach ? 0 : v) : (int32_t)x;
+                const int32_t nt = hit ? (reach ? 0 : tk) : tk;
+                const float nc = hit ? (reach ? 0.0f : now) : 1.0f;
+                const int32_t nd = hit ? (reach ? 0 : h_dic) : (m_pop ? pl : 0);
+                v = mine ? nv : v; t = mine ? nt : t; c = mine ? nc : c; d = mine ? nd : d;
+                if (mine) {
+                    L.s.po[e] = fl;
+                    if (mk) {
+                        const int p = fast_hash(mx, g.fm1) / g.bpp1;
+                        MoveEv m;
+                        m.time = 2u * pos + 1u; m.x = mx; m.cnt = mc; m.dic = md; m.kind = mk;
+                        m.pad[0] = p; m.pad[1] = m.pad[2] = 0;
+                        const uint32_t at = atomicAdd(&A.evcnt[par * g.P1 + p], 1u);
+                        if (at < (uint32_t)g.cap_ev) A.ev[(size_t)par * g.P1 * g.evs + (size_t)p * g.evs + at] = m; else over = 1;
+                        const int mi = atomicAdd(n_ev, 1);
+                        if (mi < g.evls) mine_ev[mi] = m; else over = 1;
+                    }
+                }
+                ++e;
+                act = e < nmiss && sgn == bl;
+                x = xn; pos = posn; ci = cn;
+            }
+            int32_t *dst = reinterpret_cast<int32_t *>(&stage[s]);       // store_lru, a slot per lane
+            dst[sub] = v; dst[4 + sub] = d; dst[8 + sub] = __float_as_int(c); dst[12 + sub] = t;
+            if (sub == 0) *reinterpret_cast<int4 *>(dst + 16) = make_int4((int)gflip, b0 + (int)bl, 0, 0);
+        }
+    }
+    // Phase B: buckets of long runs of one id, one per wave at a time; all 64 lanes carry the same bucket copy.  A run of
+    // probes of one id that sits in the bucket and stays below the threshold only moves its score (ordered float sum: one
+    // readlane + add per item) and its timestamp; the first probe that reaches the threshold, and every miss, takes the
+    // one-item step (sketch.cpp:165-209), executed uniformly with lane 0 writing.
     {
         const int lane = tid & 63, wave = tid >> 6;
         const int nh = min(*n_hv, kMaxHeavy);
         for (int h = wave; h < nh; h += kWaves) {
+            if (heavy[h] & kQuadTag) continue;
             const int s = heavy[h];
             const uint32_t bl = L.s.sg[s];
             LruR b;
