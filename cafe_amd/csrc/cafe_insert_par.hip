@@ -777,15 +777,20 @@ __device__ inline void hot_owner(OwnerLds<CAP, MV> &L, int *heavy, int *n_heavy,
     if (rechs) {
         // the plan left the partition in owner order (k_presort): one coalesced read, no sort on this side of the scores
         // (the first records are requested before the field sums are waited for)
-        constexpr int PRE = IPT < 8 ? IPT : 8;
+        // (the large owners are few per compute unit and have registers to spare: the whole partition in one round of
+        // record loads and one round of score loads; the small ones keep to eight records in flight)
+        constexpr int PRE = (CAP > 2048 || IPT < 8) ? IPT : 8;
         Rec rr[PRE];
 #pragma unroll
         for (int k = 0; k < PRE; ++k) { const int s = tid + k * kThreads; if (s < total) rr[k] = rechs[o0 + s]; }
         __syncthreads();                // field sums in place
+        float cc[PRE];
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) { const int s = tid + k * kThreads; cc[k] = s < total ? ss.at(rr[k].pos) : 0.0f; }
 #pragma unroll
         for (int k = 0; k < PRE; ++k) {
             const int s = tid + k * kThreads;
-            if (s < total) { L.s.sg[s] = rr[k].bl; L.s.stm[s] = 2u * rr[k].pos; L.s.pc[s] = ss.at(rr[k].pos); }
+            if (s < total) { L.s.sg[s] = rr[k].bl; L.s.stm[s] = 2u * rr[k].pos; L.s.pc[s] = cc[k]; }
         }
         for (int s = tid + PRE * kThreads; s < total; s += kThreads) {
             const Rec r = rechs[o0 + s];
