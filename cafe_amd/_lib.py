@@ -82,6 +82,9 @@ SYMBOLS = {
     "cafe_backward_update_gid_dev": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp]),
     "cafe_pack_rows_dev": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "cafe_unpack_rows_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "cafe_route_ws_words": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "cafe_route_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "cafe_split_ids_dev": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     "cafe_grad_norm_dev": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
 }
 

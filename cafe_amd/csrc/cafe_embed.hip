@@ -1679,6 +1679,120 @@ __global__ void __launch_bounds__(256) k_unpack_rows(const float *__restrict__ b
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU route (cafe_amd/sharded.py): owner rank of every lookup, the lookups in stable order by owner, the number
+// per owner.  A counting sort over `world` keys in three small launches -- per-block counts, offsets, scatter -- in
+// place of a device-wide merge sort and a dozen elementwise launches.  owner = ((gid & 0xffffffff) * 2654435761 >> 15)
+// mod world in 64-bit two's-complement arithmetic, the expression of sharded.py::owner_of (every rank and the CPU tests
+// must agree on it bit for bit).
+// ------------------------------------------------------------------------------------------------
+constexpr int kRouteBlock = 1024, kRouteWaves = kRouteBlock / 64, kRouteMaxWorld = 64;
+
+__device__ inline int route_owner(uint32_t gid, int world) {
+    const long long p = (long long)((unsigned long long)gid * 2654435761ull);
+    long long r = (p >> 15) % (long long)world;
+    if (r < 0) r += world;
+    return (int)r;
+}
+
+// mode 0: counts per (block, owner) -> ws[block * world + owner].  mode 1: the scatter, from the offsets k_route_offsets
+// left in the same array (+ the owners' bases behind it)
+template <int MODE>
+__global__ void __launch_bounds__(kRouteBlock) k_route(const int64_t *__restrict__ local_ids, const int64_t *__restrict__ id_offset,
+                                                       int batch, int n, int world, uint32_t *__restrict__ ws, int nblocks,
+                                                       int64_t *__restrict__ order, int64_t *__restrict__ packed) {
+    __shared__ uint32_t wcnt[kRouteWaves][kRouteMaxWorld];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * kRouteBlock + tid;
+    const bool live = i < n;
+    const int f = live ? i / batch : 0;
+    const uint32_t gid = live ? (uint32_t)(local_ids[i] + id_offset[f]) : 0u;        // sk_embedding_bag.py:103, as int32 bits
+    const int own = live ? route_owner(gid, world) : -1;
+    unsigned long long mine = 0;
+    for (int w = 0; w < world; ++w) {
+        const unsigned long long m = __ballot(own == w);
+        if (own == w) mine = m;
+        if (lane == 0) wcnt[wave][w] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (MODE == 0) {
+        if (tid < world) {
+            uint32_t c = 0;
+            for (int k = 0; k < kRouteWaves; ++k) c += wcnt[k][tid];
+            ws[(size_t)blockIdx.x * world + tid] = c;
+        }
+    } else if (live) {
+        uint32_t at = ws[(size_t)nblocks * world + own] + ws[(size_t)blockIdx.x * world + own];
+        for (int k = 0; k < wave; ++k) at += wcnt[k][own];
+        at += (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+        order[at] = i;
+        packed[at] = (int64_t)(((unsigned long long)(uint32_t)f << 32) | (unsigned long long)gid);
+    }
+}
+
+// one workgroup: per owner the exclusive prefix of the block counts (in place), the owners' totals and bases
+__global__ void __launch_bounds__(kRouteBlock) k_route_offsets(uint32_t *__restrict__ ws, int nblocks, int world,
+                                                               int64_t *__restrict__ send_counts) {
+    __shared__ uint32_t tot[kRouteMaxWorld];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int o = wave; o < world; o += kRouteWaves) {
+        uint32_t carry = 0;
+        for (int b0 = 0; b0 < nblocks; b0 += 64) {
+            const int b = b0 + lane;
+            const uint32_t v = b < nblocks ? ws[(size_t)b * world + o] : 0u;
+            uint32_t inc = v;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if (lane >= d) inc += x; }
+            if (b < nblocks) ws[(size_t)b * world + o] = carry + inc - v;
+            carry += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) tot[o] = carry;
+    }
+    __syncthreads();
+    if (tid < world) {
+        uint32_t base = 0;
+        for (int k = 0; k < tid; ++k) base += tot[k];
+        ws[(size_t)nblocks * world + tid] = base;
+        send_counts[tid] = (int64_t)tot[tid];
+    }
+}
+
+extern "C" int cafe_route_ws_words(int n, int world) {
+    const int nblocks = (std::max(n, 1) + kRouteBlock - 1) / kRouteBlock;
+    return (nblocks + 1) * std::max(world, 1);
+}
+
+extern "C" int cafe_route_dev(const int64_t *d_local_ids, const int64_t *d_id_offset, int num_fields, int batch, int world,
+                              uint32_t *d_ws, int64_t *d_order, int64_t *d_packed, int64_t *d_send_counts, cafe_stream_t stream) {
+    const long long n = (long long)num_fields * batch;
+    if (world < 1 || world > kRouteMaxWorld) { set_error("cafe_route_dev: world size %d outside [1, %d]", world, kRouteMaxWorld); return 1; }
+    if (num_fields <= 0 || batch <= 0 || n > 0x7fffffffLL) { set_error("cafe_route_dev: bad sizes (%d fields, batch %d)", num_fields, batch); return 1; }
+    const int nblocks = (int)((n + kRouteBlock - 1) / kRouteBlock);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_route<0>, dim3(nblocks), dim3(kRouteBlock), 0, st, d_local_ids, d_id_offset, batch, (int)n, world, d_ws, nblocks,
+                       d_order, d_packed);
+    hipLaunchKernelGGL(k_route_offsets, dim3(1), dim3(kRouteBlock), 0, st, d_ws, nblocks, world, d_send_counts);
+    hipLaunchKernelGGL(k_route<1>, dim3(nblocks), dim3(kRouteBlock), 0, st, d_local_ids, d_id_offset, batch, (int)n, world, d_ws, nblocks,
+                       d_order, d_packed);
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) k_split_ids(const int64_t *__restrict__ packed, int n, int32_t *__restrict__ gids,
+                                                   int32_t *__restrict__ fields) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long v = (unsigned long long)packed[i];
+    gids[i] = (int32_t)(uint32_t)v;
+    fields[i] = (int32_t)(uint32_t)(v >> 32);
+}
+
+extern "C" int cafe_split_ids_dev(const int64_t *d_packed, int n, int32_t *d_gids, int32_t *d_fields, cafe_stream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_split_ids, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_packed, n, d_gids, d_fields);
+    CAFE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int cafe_pack_rows_dev(const float *d_grad, const float *d_norms, const float *d_field_sums, float scale, int batch,
                                   const int64_t *d_order, int n, int dim, float *d_out, float *d_scores, cafe_stream_t stream) {
     if (n <= 0) return 0;

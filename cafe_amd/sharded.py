@@ -107,6 +107,30 @@ class HipShardBackend:
                    "cafe_pack_rows_dev")
         return send, scores
 
+    def route(self, local_ids, offsets, world):
+        """Owner of every lookup, stable order by owner, ids packed for the exchange, lookups per owner: three small
+        launches (cafe_route_dev) instead of a device-wide sort and a dozen elementwise kernels."""
+        F, B = local_ids.shape
+        n = F * B
+        words = int(self.L.cafe_route_ws_words(n, world))
+        ws = getattr(self, "_route_ws", None)
+        if ws is None or ws.numel() < words:
+            ws = self._route_ws = torch.empty(words, dtype=torch.int32, device=self.device)
+        order = torch.empty(n, dtype=torch.int64, device=self.device)
+        packed = torch.empty(n, dtype=torch.int64, device=self.device)
+        counts = torch.empty(world, dtype=torch.int64, device=self.device)
+        _lib.check(self.L.cafe_route_dev(self._p(local_ids), self._p(offsets), F, B, world, self._p(ws), self._p(order),
+                                         self._p(packed), self._p(counts), self._st()), "cafe_route_dev")
+        ws.record_stream(torch.cuda.current_stream())
+        return order, packed, counts
+
+    def split_ids(self, packed):
+        n = packed.numel()
+        gids = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        fields = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.cafe_split_ids_dev(self._p(packed), n, self._p(gids), self._p(fields), self._st()), "cafe_split_ids_dev")
+        return gids[:n], fields[:n]
+
     def unpack(self, back, order, out):
         """out[order[j]] = back[j], one launch."""
         _lib.check(self.L.cafe_unpack_rows_dev(self._p(back), self._p(order), order.numel(), self.dim, self._p(out), self._st()),
@@ -193,19 +217,23 @@ class ShardedCafeEmbedding:
         order by owner, counts exchanged, both count vectors on their way to pinned host memory."""
         F, B = local_ids.shape
         n = F * B
-        if self._fields is None or self._fields.numel() != n:
-            self._fields = torch.arange(F, device=self.device, dtype=torch.int32).repeat_interleave(B)
-        gids = (local_ids + self.offsets[:, None]).to(torch.int32).reshape(-1)      # sk_embedding_bag.py:103
-        own = owner_of(gids, self.world)
-        order = torch.argsort(own, stable=True)
-        send_counts = torch.bincount(own, minlength=self.world)
+        if hasattr(self.backend, "route") and local_ids.is_cuda:
+            order, packed, send_counts = self.backend.route(local_ids.contiguous(), self.offsets, self.world)
+        else:
+            if self._fields is None or self._fields.numel() != n:
+                self._fields = torch.arange(F, device=self.device, dtype=torch.int32).repeat_interleave(B)
+            gids = (local_ids + self.offsets[:, None]).to(torch.int32).reshape(-1)      # sk_embedding_bag.py:103
+            own = owner_of(gids, self.world)
+            order = torch.argsort(own, stable=True)
+            send_counts = torch.bincount(own, minlength=self.world)
+            packed = (self._fields[order].to(torch.int64) << 32) | (gids[order].to(torch.int64) & 0xFFFFFFFF)
         if send_counts.is_cuda and self._host_staged:
             send_counts = send_counts.cpu()
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         r = _Route()
         r.ids, r.B, r.order = local_ids, B, order
-        r.packed = (self._fields[order].to(torch.int64) << 32) | (gids[order].to(torch.int64) & 0xFFFFFFFF)
+        r.packed = packed
         r.counts_ev, r.ss, r.rs, r.ready = None, None, None, None
         if send_counts.is_cuda:
             r.counts_host = torch.empty(2, self.world, dtype=send_counts.dtype, pin_memory=True)
@@ -225,8 +253,11 @@ class ShardedCafeEmbedding:
             self.host_syncs_total += 1
             r.ss, r.rs = r.counts_host[0].tolist(), r.counts_host[1].tolist()
         got = self._a2a(r.packed, r.ss, r.rs)
-        r.r_gids = (got & 0xFFFFFFFF).to(torch.int32)          # wraps to the int32 bit pattern
-        r.r_fields = (got >> 32).to(torch.int32)
+        if hasattr(self.backend, "split_ids") and got.is_cuda:
+            r.r_gids, r.r_fields = self.backend.split_ids(got)
+        else:
+            r.r_gids = (got & 0xFFFFFFFF).to(torch.int32)          # wraps to the int32 bit pattern
+            r.r_fields = (got >> 32).to(torch.int32)
         if self._xs is not None:
             r.ready = torch.cuda.Event(); r.ready.record()
         return r

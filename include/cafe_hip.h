@@ -248,6 +248,16 @@ int cafe_backward_sgd_gid_strided_dev(cafe_tables_t *t, const int32_t *d_fields,
 int cafe_backward_update_gid_dev(cafe_sketch_t *s, cafe_tables_t *t, const int32_t *d_gids, const int32_t *d_fields,
                                  const int32_t *d_que, const float *d_rows, int row_stride, int n, float lr, int32_t *d_ins,
                                  cafe_stream_t stream);
+/* The route of a batch (no reference counterpart: the reference is single-device; cafe_amd/sharded.py): global id of
+ * every lookup (local id + id_offset[field], as int32 bits: sk_embedding_bag.py:103), its owner rank
+ * ((gid & 0xffffffff) * 2654435761 >> 15) mod world, and the lookups in stable order by owner: d_order [n] = positions in
+ * the batch, d_packed [n] = field << 32 | gid in that order (what is sent to the owners), d_send_counts [world] = lookups
+ * per owner.  d_ws: cafe_route_ws_words(n, world) 32-bit words of scratch.  world <= 64.  cafe_split_ids_dev takes
+ * received d_packed words apart into the gid and field arrays the *_gid_dev entry points read. */
+int cafe_route_ws_words(int n, int world);
+int cafe_route_dev(const int64_t *d_local_ids, const int64_t *d_id_offset, int num_fields, int batch, int world,
+                   uint32_t *d_ws, int64_t *d_order, int64_t *d_packed, int64_t *d_send_counts, cafe_stream_t stream);
+int cafe_split_ids_dev(const int64_t *d_packed, int n, int32_t *d_gids, int32_t *d_fields, cafe_stream_t stream);
 /* The two permutations around the exchanges, one launch each.  pack: d_out[j] = [d_grad[order[j]] (dim floats) | score | 0 0 0]
  * with score = d_norms[i] * scale / d_field_sums[i / batch] for i = order[j] (sk_embedding_bag.py:189 over the global
  * batch: scale = global batch size), also written to d_scores[i] when d_scores != NULL.  unpack: d_out[order[j]] =

@@ -138,3 +138,30 @@ def test_two_ranks_share_one_gpu():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}:\n{msg}"
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8, 64])
+@pytest.mark.parametrize("F,B", [(26, 8192), (3, 1000), (1, 1), (5, 1025)])
+def test_route_kernels_match_the_torch_route(world, F, B):
+    """cafe_route_dev / cafe_split_ids_dev against the plain torch route of sharded.py (owner_of, stable argsort by
+    owner, bincount, field << 32 | gid): bit-exact, ids up to the int32 wrap included."""
+    from cafe_amd.sharded import HipShardBackend, owner_of
+    dev = torch.device("cuda", 0)
+    counts = [5000] * F
+    offsets_np = (np.arange(F, dtype=np.int64) * 82_000_000)          # the last fields' ids lie beyond 2^31: negative int32 bits
+    hip = HipShardBackend([10] * F, 16, 20, [3] * F, np.zeros(F, np.int64), 2, 1, 1.0, 0, dev)
+    gen = torch.Generator(device=dev).manual_seed(F * 1000 + B + world)
+    local = torch.randint(0, 5000, (F, B), device=dev, generator=gen)
+    offsets = torch.from_numpy(offsets_np).to(dev)
+    order, packed, send = hip.route(local, offsets, world)
+    gids = (local + offsets[:, None]).to(torch.int32).reshape(-1)
+    own = owner_of(gids, world)
+    want_order = torch.argsort(own, stable=True)
+    fields = torch.arange(F, device=dev, dtype=torch.int32).repeat_interleave(B)
+    want_packed = (fields[want_order].to(torch.int64) << 32) | (gids[want_order].to(torch.int64) & 0xFFFFFFFF)
+    assert torch.equal(send, torch.bincount(own, minlength=world)), "lookups per owner"
+    assert torch.equal(order, want_order), "order"
+    assert torch.equal(packed, want_packed), "packed ids"
+    g2, f2 = hip.split_ids(packed)
+    assert torch.equal(g2, gids[want_order]) and torch.equal(f2, fields[want_order])
+    del counts
