@@ -302,9 +302,11 @@ def main():
         eng.forward(ids_dev[i % nb], out=out)
         if use_hint and not (args.drift and (i + 1) % nb == 0):
             eng.hint_next(ids_dev[(i + 1) % nb], out)      # a data loader knows its next batch: name it before the update
-        eng.backward_update(grad, args.lr, per_field_calls=cadence)
         if world > 1 and not (args.drift and (i + 1) % nb == 0):
-            eng.prefetch(ids_dev[(i + 1) % nb])       # the next batch's ids are known: route them one step ahead
+            # the next batch's ids are known: their route (owners, order, counts exchange) is queued one step ahead, before
+            # the update waits for the device's verdict
+            eng.prefetch(ids_dev[(i + 1) % nb])
+        eng.backward_update(grad, args.lr, per_field_calls=cadence)
 
     it = 0
     for _ in range(args.preheat + args.warmup):

@@ -234,7 +234,7 @@ class ShardedCafeEmbedding:
         r = _Route()
         r.ids, r.B, r.order = local_ids, B, order
         r.packed = packed
-        r.counts_ev, r.ss, r.rs, r.ready = None, None, None, None
+        r.counts_ev, r.ss, r.rs, r.ready, r.r_gids, r.r_fields = None, None, None, None, None, None
         if send_counts.is_cuda:
             r.counts_host = torch.empty(2, self.world, dtype=send_counts.dtype, pin_memory=True)
             r.counts_host[0].copy_(send_counts, non_blocking=True); r.counts_host[1].copy_(recv_counts, non_blocking=True)
@@ -285,7 +285,7 @@ class ShardedCafeEmbedding:
         if r is None or r.ids is not local_ids:
             self.host_syncs_in_step += 1
             r = self._route_finish(self._route_begin(local_ids))
-        else:
+        elif r.r_gids is None:
             if self._xs is not None:
                 with torch.cuda.stream(self._xs):
                     self._route_finish(r)
@@ -338,6 +338,13 @@ class ShardedCafeEmbedding:
                 for t in (grad_out, gn, sums, scores, send, packed):
                     t.record_stream(self._xs)
         self._join()
+        # A route queued by prefetch() is finished here (split sizes read, ids sent to their owners on the exchange stream)
+        # before the owner's step makes the host wait for the device's verdict: the next forward finds its ids delivered.
+        nxt = self._route
+        if nxt is not None and self._xs is not None and nxt.r_gids is None:
+            with torch.cuda.stream(self._xs):
+                self._route_finish(nxt)
+            nxt.packed.record_stream(self._xs)
         ins = self.backend.backward_gid(r_gids, r_fields, que, packed, lr)
         self._last = (r_gids, r_fields, packed[:, D], ins)
         return scores.reshape(-1), ins

@@ -25,8 +25,12 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 
 def step(i):
     eng.forward(ids[i % 16], out=out)
-    eng.backward_update(grad, 0.1)
-    eng.prefetch(ids[(i + 1) % 16])
+    if os.environ.get("PREFETCH_LATE"):
+        eng.backward_update(grad, 0.1)
+        eng.prefetch(ids[(i + 1) % 16])
+    else:
+        eng.prefetch(ids[(i + 1) % 16])      # the next batch's ids are known: its route is queued before the update's verdict wait
+        eng.backward_update(grad, 0.1)
 
 
 for i in range(n):
