@@ -17,19 +17,20 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 wl = workload(sys.argv[1] if len(sys.argv) > 1 else "cfg3")
 F, B, D = wl.num_fields, wl.batch, wl.dim
 eng = ShardedCafeEmbedding(wl.counts, D, wl.hotn, wl.hash_sizes, wl.offsets, threshold=wl.threshold, alpha=wl.alpha, seed=1)
-ids = [torch.from_numpy(x).cuda() for x in wl.make_ids(123, steps=16)]
+NB = int(os.environ.get("NB", "64"))
+ids = [torch.from_numpy(x).cuda() for x in wl.make_ids(123, steps=NB)]
 grad = torch.randn(F, B, D, device="cuda")
 out = torch.empty(F, B, D, device="cuda")
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 
 
 def step(i):
-    eng.forward(ids[i % 16], out=out)
+    eng.forward(ids[i % NB], out=out)
     if os.environ.get("PREFETCH_LATE"):
         eng.backward_update(grad, 0.1)
-        eng.prefetch(ids[(i + 1) % 16])
+        eng.prefetch(ids[(i + 1) % NB])
     else:
-        eng.prefetch(ids[(i + 1) % 16])      # the next batch's ids are known: its route is queued before the update's verdict wait
+        eng.prefetch(ids[(i + 1) % NB])      # the next batch's ids are known: its route is queued before the update's verdict wait
         eng.backward_update(grad, 0.1)
 
 
