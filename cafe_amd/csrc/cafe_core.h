@@ -444,6 +444,19 @@ __device__ inline void store_through16(void *p, float4 v) {
 #endif
 }
 
+// non-temporal form
+__device__ inline void store_nt16(void *p, float4 v) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(x) : "memory");
+}
+
+__device__ inline float4 load_nt16(const void *p) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f x = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return make_float4(x.x, x.y, x.z, x.w);
+}
+
 }  // namespace cafe
 
 // Diagnostic build (make EXTRA=-DCAFE_PROF): thread 0 of every workgroup of a numbered kernel stamps the 100 MHz wall

@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
                                                  int32_t *__restrict__ gids, int32_t *__restrict__ que,
                                                  float *__restrict__ out, const float *__restrict__ w_med = nullptr,
                                                  int median_n = 1, const DevState *__restrict__ st = nullptr, int gflip = 0,
-                                                 int32_t *__restrict__ qmed = nullptr) {
+                                                 int32_t *__restrict__ qmed = nullptr, int wl = 64, int nt = 0) {
     CAFE_KWIN(0);
     // A wave takes 64 consecutive lookups.  First every lane resolves one lookup on its own (id, one 32-B probe of
     // val|dic, routing, source row address): three dependent memory steps for 64 lookups instead of per lookup.  Then
@@ -166,11 +166,11 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
     const int dim4 = dim >> 2;
     const int lig = lane % LPG, sub = lane / LPG;
-    for (int base = wave * 64; base < total; base += waves * 64) {
+    for (int base = wave * wl; base < total; base += waves * wl) {
         const int i = base + lane;
         const float *row = nullptr;
         const float *row2 = nullptr;
-        if (i < total) {
+        if (i < total && lane < wl) {
             const int f = fields ? fields[i] : i / batch;
             const int32_t g = local_ids ? (int32_t)(local_ids[i] + id_offset[f]) : in_gids[i];      // sk_embedding_bag.py:103
             const uint32_t x = (uint32_t)g;
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
         const int lo = (int)(uint32_t)ra, hi = (int)(uint32_t)(ra >> 32);
         const unsigned long long rb = (unsigned long long)row2;
         const int lo2 = (int)(uint32_t)rb, hi2 = (int)(uint32_t)(rb >> 32);
-        const int nrow = min(64, total - base);
+        const int nrow = min(wl, total - base);
         float4 *obase = reinterpret_cast<float4 *>(out + (size_t)base * dim);
         for (int c0 = 0; c0 < dim4; c0 += LPG) {
             const int c = c0 + lig;
@@ -218,7 +218,10 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int r = j + u * RPI + sub;
-                    if (r < nrow && c < dim4) cafe::store_through16(&obase[(size_t)r * dim4 + c], t[u]);
+                    if (r < nrow && c < dim4) {
+                        if (nt) cafe::store_nt16(&obase[(size_t)r * dim4 + c], t[u]);
+                        else cafe::store_through16(&obase[(size_t)r * dim4 + c], t[u]);
+                    }
                 }
             }
         }
@@ -262,7 +265,18 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     const double t_begin = now_us();
     const int total = (int)total_l;
     const int lpg = lanes_per_row(t->dim);
-    const int blocks = (int)std::min<long>(((long)total + 255) / 256, 256 * 16);      // a wave per 64 lookups
+    // (32 lookups per wave instead of 64: twice the waves, half the copy rounds per wave; cfg3 -1 %)
+    static const int fwd_wl_env = getenv("CAFE_FWD_WL") ? atoi(getenv("CAFE_FWD_WL")) : 32;
+    // The gathered rows leave as NON-TEMPORAL stores: 109 MB per step at D = 128 that nothing in the library reads again;
+    // written through the caches (sc1) they push out what the following kernels want there -- the gradient, the hot
+    // rows.  cfg3: 0.1824 -> 0.1744 ms per step, the norm kernel behind the gather 29 -> 24.5 us (tools/micro/wr.hip: a
+    // gather-copy of 213 k random 512-byte rows takes 26.7 us with nt stores, 34.7 us with sc1).  CAFE_FWD_NT=0: sc1.
+    // (the gid form -- a shard's gather, whose rows the all-to-all reads at once -- keeps sc1: the sharded step is 8 % slower
+    // with nt there)
+    static const int fwd_nt_env = getenv("CAFE_FWD_NT") ? atoi(getenv("CAFE_FWD_NT")) : 1;
+    const int fwd_nt = (fwd_nt_env == 1 && !d_local_ids) ? 0 : (fwd_nt_env ? 1 : 0);
+    const int fwd_wl = std::min(64, std::max(8, fwd_wl_env));
+    const int blocks = (int)std::min<long>(((long)total + 4 * fwd_wl - 1) / (4 * fwd_wl), 256 * 64);      // a wave per fwd_wl lookups
     FastMod fm1 = make_fastmod(s->n1);
     // Training steps: the plan of the insert that will follow (it reads the ids and the same pre-batch tables the gather
     // reads) runs beside the gather on the sketch's second stream, behind everything queued on `st` so far.  Stopped
@@ -308,7 +322,8 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     hipExtLaunchKernelGGL((k_forward<L, false>), dim3(blocks), dim3(256), 0, st, nullptr, fwd_done, 0,           \
                           (const MainBucket *)s->d_main, fm1, (const float *)t->d_w_hot, (float *const *)t->d_w_cold, \
                           (const int64_t *)t->d_id_offset, (const int32_t *)t->d_hash_size, d_local_ids, d_in_gids, d_fields, batch, total, \
-                          t->dim, t->hotn, d_gids, d_que, d_out, (const float *)nullptr, 1, (const DevState *)nullptr, 0, (int32_t *)nullptr)
+                          t->dim, t->hotn, d_gids, d_que, d_out, (const float *)nullptr, 1, (const DevState *)nullptr, 0, (int32_t *)nullptr, \
+                          fwd_wl, fwd_nt)
     t->fwd_epoch++;
     if (t->timing) { (void)hipEventRecord(t->ev_t[0][0], st); t->ev_epoch[0] = t->fwd_epoch; }
     switch (lpg) {
@@ -905,7 +920,7 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                                                       float *__restrict__ w_hot, float *const *__restrict__ w_cold,
                                                       const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr,
                                                       const uint32_t *__restrict__ skip_rej, uint32_t skip_seq, int gstride,
-                                                      uint4 *__restrict__ entries, float4 *__restrict__ sums) {
+                                                      uint4 *__restrict__ entries, float4 *__restrict__ sums, int ntld) {
     CAFE_KWIN(6);
     __shared__ __attribute__((aligned(16))) unsigned long long key[kBwdCap];
     __shared__ float4 bpart[2][VPL][256];      // border partial sums: [0] head of a group's range, [1] tail
@@ -1012,7 +1027,7 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
 #pragma unroll
                 for (int v = 0; v < VPL; ++v) {
                     const int c = lig + v * LPG;
-                    gr[e][v] = (live && c < dim4) ? g[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    gr[e][v] = (live && c < dim4) ? (ntld ? cafe::load_nt16(&g[c]) : g[c]) : make_float4(0.f, 0.f, 0.f, 0.f);
                     if constexpr (!EMIT)
                         wr[e][v] = (m == 1u && c < dim4) ? reinterpret_cast<const float4 *>(rowp[e])[c]
                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1147,7 +1162,7 @@ __global__ void __launch_bounds__(256) k_bwd_compact(int total, const uint4 *__r
 template <int LPG, int VPL>
 __global__ void __launch_bounds__(256) k_bwd_apply(const uint32_t *__restrict__ ecount, const uint4 *__restrict__ list,
                                                    const float4 *__restrict__ sums, int dim, float lr,
-                                                   const uint32_t *__restrict__ skip_rej, uint32_t skip_seq) {
+                                                   const uint32_t *__restrict__ skip_rej, uint32_t skip_seq, int nt) {
     CAFE_KWIN(7);
     if (skip_rej && *skip_rej == skip_seq) return;       // see k_bwd_segments
     constexpr int G = 256 / LPG;
@@ -1161,7 +1176,7 @@ __global__ void __launch_bounds__(256) k_bwd_apply(const uint32_t *__restrict__ 
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
             const int c = lig + v * LPG;
-            sm[v] = c < dim4 ? sums[(size_t)en.w * dim4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            sm[v] = c < dim4 ? ((nt & 2) ? cafe::load_nt16(&sums[(size_t)en.w * dim4 + c]) : sums[(size_t)en.w * dim4 + c]) : make_float4(0.f, 0.f, 0.f, 0.f);
             w[v] = (c < dim4 && en.z == 1u) ? reinterpret_cast<const float4 *>(row)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -1170,7 +1185,8 @@ __global__ void __launch_bounds__(256) k_bwd_apply(const uint32_t *__restrict__ 
             if (c >= dim4) continue;
             if (en.z == 1u) {
                 w[v].x -= lr * sm[v].x; w[v].y -= lr * sm[v].y; w[v].z -= lr * sm[v].z; w[v].w -= lr * sm[v].w;
-                cafe::store_through16(&reinterpret_cast<float4 *>(row)[c], w[v]);
+                if (nt & 1) cafe::store_nt16(&reinterpret_cast<float4 *>(row)[c], w[v]);
+                else cafe::store_through16(&reinterpret_cast<float4 *>(row)[c], w[v]);
             } else {
 #ifndef CAFE_NO_ATOMIC
                 float *r = row + c * 4;
@@ -1240,9 +1256,10 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     // a lane, leave every compute unit room for one workgroup of the insert's persistent tail kernel (128 registers),
     // whose grid barriers need all of its workgroups resident.
     static const int emit_grid = getenv("CAFE_EMIT_GRID") ? atoi(getenv("CAFE_EMIT_GRID")) : 1024;
+    static const int seg_ntld = getenv("CAFE_SEG_NTLD") ? atoi(getenv("CAFE_SEG_NTLD")) : 0;       // the gradient's last read: non-temporal
 #define CAFE_SEG(L, V, E)                                                                                                \
     hipLaunchKernelGGL((k_bwd_segments<L, V, E>), dim3(E ? std::min(grid, emit_grid) : grid), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
-                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_rej, skip_seq, gs, entries, sums)
+                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_rej, skip_seq, gs, entries, sums, seg_ntld)
 #define CAFE_SEG_ALL(E)                                                                                                  \
     if (vpl == 1) {                                                                                                      \
         switch (lpg) {                                                                                                   \
@@ -1291,9 +1308,11 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         // a lane group per row; the rows of a step are at most its lookups, usually a fraction of them
         const int G = 256 / lpg;
         const int agrid = std::max(1, std::min((total + G - 1) / G, 4096));
+        // bit 0: row stores non-temporal (slower: the next gather reads hot rows), bit 1: the sums are read once (cfg3 -1 %)
+        static const int apply_nt = getenv("CAFE_APPLY_NT") ? atoi(getenv("CAFE_APPLY_NT")) : 2;
         if (t->timing) { (void)hipEventRecord(t->ev_t[4][0], st); t->ev_epoch[4] = t->bwd_epoch; }
 #define CAFE_APPLY(L, V)                                                                                                 \
-    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, t->dim, lr, skip_rej, skip_seq)
+    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, t->dim, lr, skip_rej, skip_seq, apply_nt)
         if (vpl == 1) {
             switch (lpg) {
                 case 1: CAFE_APPLY(1, 1); break;
