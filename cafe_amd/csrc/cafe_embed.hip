@@ -145,7 +145,7 @@ static inline int lanes_per_row(int dim) {
 // ------------------------------------------------------------------------------------------------
 // ML = the three-tier variant of tricks/sketch_ml_embed.py:154-199: a cold lookup of medium importance adds the row
 // of a second hash table (W_median[gid % median_n]) to its cold row.
-template <int LPG, bool ML = false>
+template <int LPG, bool ML = false, int WL = 64, bool NT = false>
 __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ mt, FastMod fm1,
                                                  const float *__restrict__ w_hot, float *const *__restrict__ w_cold,
                                                  const int64_t *__restrict__ id_offset, const int32_t *__restrict__ hash_size,
@@ -155,8 +155,10 @@ __global__ void __launch_bounds__(256) k_forward(const MainBucket *__restrict__ 
                                                  int32_t *__restrict__ gids, int32_t *__restrict__ que,
                                                  float *__restrict__ out, const float *__restrict__ w_med = nullptr,
                                                  int median_n = 1, const DevState *__restrict__ st = nullptr, int gflip = 0,
-                                                 int32_t *__restrict__ qmed = nullptr, int wl = 64, int nt = 0) {
+                                                 int32_t *__restrict__ qmed = nullptr) {
     CAFE_KWIN(0);
+    constexpr int wl = WL;
+    constexpr bool nt = NT;
     // A wave takes 64 consecutive lookups.  First every lane resolves one lookup on its own (id, one 32-B probe of
     // val|dic, routing, source row address): three dependent memory steps for 64 lookups instead of per lookup.  Then
     // the wave copies the 64 rows, 64/LPG rows per instruction (LPG lanes x float4 = one row), eight instructions in
@@ -266,7 +268,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     const int total = (int)total_l;
     const int lpg = lanes_per_row(t->dim);
     // (32 lookups per wave instead of 64: twice the waves, half the copy rounds per wave; cfg3 -1 %)
-    static const int fwd_wl_env = getenv("CAFE_FWD_WL") ? atoi(getenv("CAFE_FWD_WL")) : 32;
+    constexpr int kFwdWl = 32;
     // The gathered rows leave as NON-TEMPORAL stores: 109 MB per step at D = 128 that nothing in the library reads again;
     // written through the caches (sc1) they push out what the following kernels want there -- the gradient, the hot
     // rows.  cfg3: 0.1824 -> 0.1744 ms per step, the norm kernel behind the gather 29 -> 24.5 us (tools/micro/wr.hip: a
@@ -275,7 +277,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     // with nt there)
     static const int fwd_nt_env = getenv("CAFE_FWD_NT") ? atoi(getenv("CAFE_FWD_NT")) : 1;
     const int fwd_nt = (fwd_nt_env == 1 && !d_local_ids) ? 0 : (fwd_nt_env ? 1 : 0);
-    const int fwd_wl = std::min(64, std::max(8, fwd_wl_env));
+    const int fwd_wl = kFwdWl;
     const int blocks = (int)std::min<long>(((long)total + 4 * fwd_wl - 1) / (4 * fwd_wl), 256 * 64);      // a wave per fwd_wl lookups
     FastMod fm1 = make_fastmod(s->n1);
     // Training steps: the plan of the insert that will follow (it reads the ids and the same pre-batch tables the gather
@@ -319,11 +321,12 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
     s->fwd_que = d_que;
     s->fwd_count++;
 #define CAFE_FWD(L)                                                                                              \
-    hipExtLaunchKernelGGL((k_forward<L, false>), dim3(blocks), dim3(256), 0, st, nullptr, fwd_done, 0,           \
+    if (fwd_nt) CAFE_FWD2(L, true); else CAFE_FWD2(L, false)
+#define CAFE_FWD2(L, N)                                                                                          \
+    hipExtLaunchKernelGGL((k_forward<L, false, kFwdWl, N>), dim3(blocks), dim3(256), 0, st, nullptr, fwd_done, 0,           \
                           (const MainBucket *)s->d_main, fm1, (const float *)t->d_w_hot, (float *const *)t->d_w_cold, \
                           (const int64_t *)t->d_id_offset, (const int32_t *)t->d_hash_size, d_local_ids, d_in_gids, d_fields, batch, total, \
-                          t->dim, t->hotn, d_gids, d_que, d_out, (const float *)nullptr, 1, (const DevState *)nullptr, 0, (int32_t *)nullptr, \
-                          fwd_wl, fwd_nt)
+                          t->dim, t->hotn, d_gids, d_que, d_out, (const float *)nullptr, 1, (const DevState *)nullptr, 0, (int32_t *)nullptr)
     t->fwd_epoch++;
     if (t->timing) { (void)hipEventRecord(t->ev_t[0][0], st); t->ev_epoch[0] = t->fwd_epoch; }
     switch (lpg) {
@@ -336,6 +339,7 @@ static int forward_common(cafe_sketch_t *s, cafe_tables_t *t, const int64_t *d_l
         default: CAFE_FWD(64); break;
     }
 #undef CAFE_FWD
+#undef CAFE_FWD2
     if (t->timing) (void)hipEventRecord(t->ev_t[0][1], st);
     CAFE_HIP_CHECK(hipGetLastError());
     if (plan && !plan_launched) {
