@@ -1166,15 +1166,19 @@ __global__ void __launch_bounds__(256) k_bwd_compact(int total, const uint4 *__r
 template <int LPG, int VPL>
 __global__ void __launch_bounds__(256) k_bwd_apply(const uint32_t *__restrict__ ecount, const uint4 *__restrict__ list,
                                                    const float4 *__restrict__ sums, int dim, float lr,
-                                                   const uint32_t *__restrict__ skip_rej, uint32_t skip_seq, int nt) {
+                                                   const uint32_t *__restrict__ skip_rej, uint32_t skip_seq, int nt, uint32_t cap) {
     CAFE_KWIN(7);
-    if (skip_rej && *skip_rej == skip_seq) return;       // see k_bwd_segments
     constexpr int G = 256 / LPG;
     const int lig = threadIdx.x % LPG, grp = threadIdx.x / LPG;
     const int dim4 = dim >> 2;
+    // the group's first list entry is requested together with the row count and the verdict word (the list has room for
+    // `cap` entries; one beyond the count is read and not used): one memory round trip less before the first row moves
+    const uint32_t i0 = blockIdx.x * G + grp;
+    uint4 en = i0 < cap ? list[i0] : make_uint4(0u, 0u, 0u, 0u);
     const uint32_t n = *ecount;
-    for (uint32_t i = blockIdx.x * G + grp; i < n; i += gridDim.x * G) {
-        const uint4 en = list[i];
+    if (skip_rej && *skip_rej == skip_seq) return;       // see k_bwd_segments
+    for (uint32_t i = i0; i < n; i += gridDim.x * G) {
+        if (i != i0) en = list[i];
         float *row = reinterpret_cast<float *>(((unsigned long long)en.y << 32) | en.x);
         float4 sm[VPL], w[VPL];
 #pragma unroll
@@ -1316,7 +1320,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         static const int apply_nt = getenv("CAFE_APPLY_NT") ? atoi(getenv("CAFE_APPLY_NT")) : 2;
         if (t->timing) { (void)hipEventRecord(t->ev_t[4][0], st); t->ev_epoch[4] = t->bwd_epoch; }
 #define CAFE_APPLY(L, V)                                                                                                 \
-    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, t->dim, lr, skip_rej, skip_seq, apply_nt)
+    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, t->dim, lr, skip_rej, skip_seq, apply_nt, (uint32_t)total)
         if (vpl == 1) {
             switch (lpg) {
                 case 1: CAFE_APPLY(1, 1); break;
