@@ -783,6 +783,7 @@ constexpr int kBwdCap = 256;        // items a workgroup sorts in LDS, one per l
 constexpr int kBwdMaxBins = 8192;
 constexpr int kBwdTarget = 160;     // average items per partition: a partition without a heavy row fits one tile
 constexpr int kBwdCH = 8;           // items a lane group takes at a time
+constexpr int kListRegions = 64;    // split update: the row list is kept in this many regions, a counter each (tile t claims in region t mod 64)
 
 __device__ inline uint32_t row_key(const int32_t *__restrict__ fields, const int32_t *__restrict__ que,
                                    const int32_t *__restrict__ hash_size, const int64_t *__restrict__ cold_base, int hotn,
@@ -831,7 +832,7 @@ __global__ void __launch_bounds__(1024) k_bwd_offsets(int Ph, int P, const uint3
                                                       uint32_t *__restrict__ tiles /* [0] = hot tiles, [1] = all tiles, then (p << 8 | t)... */,
                                                       uint32_t *__restrict__ ecount) {
     CAFE_KWIN(4);
-    if (threadIdx.x == 0 && ecount) *ecount = 0;        // rows of the split update (counted by k_bwd_compact)
+    if (threadIdx.x < kListRegions && ecount) ecount[threadIdx.x] = 0;        // rows of the split update, per list region
     __shared__ uint32_t sh[1024], sh2[1024];
     __shared__ uint32_t carry, carry2;
     if (threadIdx.x == 0) { carry = 0; carry2 = 0; }
@@ -924,9 +925,13 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                                                       float *__restrict__ w_hot, float *const *__restrict__ w_cold,
                                                       const int64_t *__restrict__ cold_base, int hotn, int batch, int dim, float lr,
                                                       const uint32_t *__restrict__ skip_rej, uint32_t skip_seq, int gstride,
-                                                      uint4 *__restrict__ entries, float4 *__restrict__ sums, int ntld) {
+                                                      uint4 *__restrict__ entries, float4 *__restrict__ sums, int ntld,
+                                                      uint32_t *__restrict__ ecount, uint4 *__restrict__ list, uint32_t rcap) {
     CAFE_KWIN(6);
+    (void)entries;
     __shared__ __attribute__((aligned(16))) unsigned long long key[kBwdCap];
+    __shared__ uint4 lent[EMIT ? kBwdCap : 1];        // EMIT: the tile's list entries, flushed to the claimed place at its end
+    __shared__ uint32_t s_all, s_lbase;
     __shared__ float4 bpart[2][VPL][256];      // border partial sums: [0] head of a group's range, [1] tail
     __shared__ int bflag[256];
     __shared__ uint16_t srank[EMIT ? kBwdCap : 2];     // EMIT: rows that start before sorted position j
@@ -936,6 +941,7 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
     // names that call) the host issues the step again, and this update with it
     if (skip_rej && *skip_rej == skip_seq) return;
     const uint32_t ntiles = tiles[1];
+    uint32_t claim = 0, region = 0;
     for (uint32_t tile_at = blockIdx.x; tile_at < ntiles; tile_at += gridDim.x) {
     // the tile index is kept in 8 bits; a partition with more tiles lets its last workgroup walk the rest
     const uint32_t tl = tiles[2 + tile_at];
@@ -973,10 +979,18 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
             uint32_t before = 0, all = 0;
             for (int w = 0; w < 4; ++w) { const uint32_t c = wrows[w]; all += c; if (w < wave) before += c; }
             srank[tid] = (uint16_t)(before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
-            // the tile's rows take the first `all` of the tile's n entries (entry = position in the partitioned order: no
-            // counter to contend for); the others are marked empty
-            if (tid == 0) s_ebase = o0 + (uint32_t)t0;
-            if (tid >= (int)all && tid < n) entries[o0 + t0 + tid] = make_uint4(0u, 0u, 0u, 0u);
+            // A row's sum lives at the tile's place in the partitioned order + its rank among the tile's rows (no counter to
+            // contend for).  Its LIST entry -- row address, kind, where the sum is: what k_bwd_apply walks -- goes to a place
+            // claimed with ONE atomic per tile, issued here and not needed before the tile's end; the entries wait in LDS
+            // meanwhile.  The list is kept in kListRegions regions with a counter each: all workgroups claim at the same
+            // moment, and a thousand atomics on ONE address took 12 us to drain, during which the wave that issued one could
+            // not receive its gradient rows either (returns are in order).  (Until round 3 a kernel of its own compacted
+            // the entries between the gradient pass and the row updates: 7.5 us on the step's critical path.)
+            if (tid == 0) {
+                s_ebase = o0 + (uint32_t)t0; s_all = all;
+                region = (tile_at + (uint32_t)(t0 / kBwdCap - tile)) & (kListRegions - 1);
+                claim = all ? atomicAdd(&ecount[region], all) : 0u;
+            }
             __syncthreads();
         }
         BWD_STAMP(1);
@@ -1020,8 +1034,11 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                         if (head && tail) m = 5u;                    // the whole range is the middle of one row's run
                         if constexpr (EMIT) {
                             // the row starts at ss (in this group's range unless it is a head partial)
-                            slot_of[e] = ebase + srank[ss];
-                            if ((m == 1u || m == 2u || m == 4u) && lig == 0) entries[slot_of[e]] = make_uint4(k, i, (m == 2u || multi) ? 2u : 1u, 0u);
+                            const uint32_t lrank = srank[ss];
+                            slot_of[e] = ebase + lrank;
+                            if ((m == 1u || m == 2u || m == 4u) && lig == 0) {
+                                lent[lrank] = make_uint4(k, i, (m == 2u || multi) ? 2u : 1u, slot_of[e]);       // row key, a lookup of the row
+                            }
                         }
                         ss = begin + e + 1;
                     }
@@ -1116,70 +1133,52 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
                 }
             }
         }
+        if constexpr (EMIT) {
+            if (tid == 0) s_lbase = region * rcap + claim;
+            __syncthreads();
+            if (tid < (int)s_all) list[s_lbase + tid] = lent[tid];
+        }
     }
     __syncthreads();
     }
     BWD_STAMP(2);
 }
 
-// Between the two halves of the split update: the non-empty entries, gathered into a list (one counter update per
-// 1024 entries).  list[i] = {address of the table row (two words), 1 plain / 2 atomic, entry index = where the row's sum
-// is}: the address is worked out here, beside the insert, so the update kernel behind the migration starts with it.
-__global__ void __launch_bounds__(256) k_bwd_compact(int total, const uint4 *__restrict__ entries, uint32_t *__restrict__ ecount,
-                                                     uint4 *__restrict__ list, const int32_t *__restrict__ fields,
-                                                     float *__restrict__ w_hot, float *const *__restrict__ w_cold,
-                                                     const int64_t *__restrict__ cold_base, int hotn, int batch, int dim) {
-    __shared__ uint32_t wcnt[4], s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int e0 = (blockIdx.x * 256 + tid) * 4;
-    uint4 en[4];
-    uint32_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        en[k] = e0 + k < total ? entries[e0 + k] : make_uint4(0u, 0u, 0u, 0u);
-        mine += en[k].z != 0u;
-    }
-    uint32_t inc = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += v;
-    }
-    if (lane == 63) wcnt[wave] = inc;
-    __syncthreads();
-    uint32_t before = 0, all = 0;
-    for (int w = 0; w < 4; ++w) { const uint32_t c = wcnt[w]; all += c; if (w < wave) before += c; }
-    if (tid == 0) s_base = all ? atomicAdd(ecount, all) : 0u;
-    __syncthreads();
-    uint32_t at = s_base + before + inc - mine;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (en[k].z != 0u) {
-            const unsigned long long a = (unsigned long long)row_ptr(en[k].x, en[k].y, fields, w_hot, w_cold, cold_base, hotn, batch, dim);
-            list[at++] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), en[k].z, (uint32_t)(e0 + k));
-        }
-}
-
-// Second half of the split update: list entry = one table row, W[row] -= lr * sums[entry] (plain read-modify-write;
+// Second half of the split update: list entry = {row key, a lookup of the row, 1 plain / 2 atomic, where the row's sum is};
+// W[row] -= lr * sums[entry] (plain read-modify-write;
 // float atomics for the rows of a partition that was walked in several tiles, as in the one-kernel form).  A lane group
 // per row, grid-stride over the *ecount rows of the list.
 template <int LPG, int VPL>
 __global__ void __launch_bounds__(256) k_bwd_apply(const uint32_t *__restrict__ ecount, const uint4 *__restrict__ list,
                                                    const float4 *__restrict__ sums, int dim, float lr,
-                                                   const uint32_t *__restrict__ skip_rej, uint32_t skip_seq, int nt, uint32_t cap) {
+                                                   const uint32_t *__restrict__ skip_rej, uint32_t skip_seq, int nt, uint32_t cap,
+                                                   const int32_t *__restrict__ fields, float *__restrict__ w_hot,
+                                                   float *const *__restrict__ w_cold, const int64_t *__restrict__ cold_base, int hotn,
+                                                   int batch) {
     CAFE_KWIN(7);
     constexpr int G = 256 / LPG;
     const int lig = threadIdx.x % LPG, grp = threadIdx.x / LPG;
     const int dim4 = dim >> 2;
-    // the group's first list entry is requested together with the row count and the verdict word (the list has room for
-    // `cap` entries; one beyond the count is read and not used): one memory round trip less before the first row moves
-    const uint32_t i0 = blockIdx.x * G + grp;
-    uint4 en = i0 < cap ? list[i0] : make_uint4(0u, 0u, 0u, 0u);
-    const uint32_t n = *ecount;
-    if (skip_rej && *skip_rej == skip_seq) return;       // see k_bwd_segments
-    for (uint32_t i = i0; i < n; i += gridDim.x * G) {
-        if (i != i0) en = list[i];
-        float *row = reinterpret_cast<float *>(((unsigned long long)en.y << 32) | en.x);
+    // the list's regions (k_bwd_segments) as one sequence: prefix of the region counters, then row i lies in the region
+    // whose range holds i (`cap` = entries a region has room for)
+    __shared__ uint32_t pre[kListRegions + 1];
+    if (threadIdx.x < 64) {
+        const uint32_t c = ecount[threadIdx.x];
+        uint32_t inc = c;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)threadIdx.x >= d) inc += x; }
+        pre[threadIdx.x + 1] = inc;
+        if (threadIdx.x == 0) pre[0] = 0;
+    }
+    const bool skip = skip_rej && *skip_rej == skip_seq;       // see k_bwd_segments
+    __syncthreads();
+    if (skip) return;
+    const uint32_t n = pre[kListRegions];
+    for (uint32_t i = blockIdx.x * G + grp; i < n; i += gridDim.x * G) {
+        int r = 0;
+#pragma unroll
+        for (int b = kListRegions / 2; b > 0; b >>= 1) r += (pre[r + b] <= i) ? b : 0;
+        const uint4 en = list[(size_t)r * cap + (i - pre[r])];
+        float *row = row_ptr(en.x, en.y, fields, w_hot, w_cold, cold_base, hotn, batch, dim);
         float4 sm[VPL], w[VPL];
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
@@ -1230,14 +1229,17 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     if (t->ws_bwd_b.reserve(4 * (size_t)kBwdMaxBins + 16) || t->ws_misc.reserve(4 * (size_t)max_tiles + 32) ||
         t->ws_bwd_c.reserve(8 * (size_t)total) ||
         t->ws_bwd_d.reserve(8 * (size_t)total)) return 1;
-    if ((part & 28) && (t->ws_bwd_e.reserve(32 * (size_t)total + 64) || t->ws_bwd_f.reserve(4 * (size_t)total * t->dim + 64))) return 1;
+    // split form: kListRegions row counters, then the row list in as many regions of rcap entries (a region holds the rows
+    // of every 64th tile; tiles beyond a partition's 255th -- a row with more than 65 k lookups -- are spread likewise)
+    const uint32_t rcap = (uint32_t)(max_tiles / kListRegions + total / 65536 + 4) * kBwdCap;
+    if ((part & 28) && (t->ws_bwd_e.reserve(256 + 16 * (size_t)kListRegions * rcap + 64) || t->ws_bwd_f.reserve(4 * (size_t)total * t->dim + 64))) return 1;
     uint32_t *cnt = t->ws_bwd_a.as<uint32_t>(), *off = t->ws_bwd_b.as<uint32_t>();
     uint32_t *rank = t->ws_bwd_c.as<uint32_t>(), *keys = rank + total;
     unsigned long long *items = t->ws_bwd_d.as<unsigned long long>();
     uint32_t *tiles = t->ws_misc.as<uint32_t>();
-    // split form: [0] the entry counter (zeroed by the offsets pass of every step), entries from byte 64
+    // (the counters are zeroed by the offsets pass of every step; the list starts at byte 256)
     uint32_t *ecount = t->ws_bwd_e.p ? t->ws_bwd_e.as<uint32_t>() : nullptr;
-    uint4 *entries = ecount ? reinterpret_cast<uint4 *>(ecount + 16) : nullptr, *elist = entries ? entries + total : nullptr;
+    uint4 *entries = nullptr, *elist = ecount ? reinterpret_cast<uint4 *>(ecount + 64) : nullptr;
     float4 *sums = t->ws_bwd_f.p ? t->ws_bwd_f.as<float4>() : nullptr;
     if (part & 1) {
         // The partition workspaces are one set per tables handle.  Passes queued earlier on another stream (a forward's, on
@@ -1266,8 +1268,10 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     static const int emit_grid = getenv("CAFE_EMIT_GRID") ? atoi(getenv("CAFE_EMIT_GRID")) : 1024;
     static const int seg_ntld = getenv("CAFE_SEG_NTLD") ? atoi(getenv("CAFE_SEG_NTLD")) : 0;       // the gradient's last read: non-temporal
 #define CAFE_SEG(L, V, E)                                                                                                \
-    hipLaunchKernelGGL((k_bwd_segments<L, V, E>), dim3(E ? std::min(grid, emit_grid) : grid), dim3(256), 0, st, off, tiles, items, d_fields, d_grad_out, t->d_w_hot, \
-                       t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim, lr, skip_rej, skip_seq, gs, entries, sums, seg_ntld)
+    hipExtLaunchKernelGGL((k_bwd_segments<L, V, E>), dim3(E ? std::min(grid, emit_grid) : grid), dim3(256), 0, st, nullptr, E ? t->ev_sums : nullptr, 0, \
+                          (const uint32_t *)off, (const uint32_t *)tiles, (const unsigned long long *)items, d_fields, d_grad_out, t->d_w_hot, \
+                          (float *const *)t->d_w_cold, (const int64_t *)t->d_cold_base, t->hotn, batch, t->dim, lr, skip_rej, skip_seq, gs, entries, sums, \
+                          seg_ntld, ecount, elist, rcap)
 #define CAFE_SEG_ALL(E)                                                                                                  \
     if (vpl == 1) {                                                                                                      \
         switch (lpg) {                                                                                                   \
@@ -1293,18 +1297,17 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
     if (part & 4) {
         if (pst != st) CAFE_HIP_CHECK(hipStreamWaitEvent(st, t->ev_plan, 0));
         if (t->timing) { (void)hipEventRecord(t->ev_t[1][0], st); t->ev_epoch[1] = t->bwd_epoch; }
+        // (the completion event of the sums and the list rides on the kernel itself: no marker packet between it and the
+        // waiting stream)
+        if (!t->ev_sums) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_sums, kDeviceEvent));
         CAFE_SEG_ALL(true)
         if (t->timing) (void)hipEventRecord(t->ev_t[1][1], st);          // the gradient pass alone (as a profiler reports it)
-        // (the list's completion event rides on the kernel itself: no marker packet between it and the waiting stream)
-        if (!t->ev_sums) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_sums, kDeviceEvent));
-        hipExtLaunchKernelGGL(k_bwd_compact, dim3((total + 1023) / 1024), dim3(256), 0, st, nullptr, t->ev_sums, 0, total, (const uint4 *)entries,
-                              ecount, elist, d_fields, t->d_w_hot, t->d_w_cold, t->d_cold_base, t->hotn, batch, t->dim);
         // the row count for the host's rule: copied to pinned memory behind the list kernel, read by a later step once the
         // event behind the copy reports it landed (never waited for; no new copy while one is in flight)
-        if (!t->h_rows) { CAFE_HIP_CHECK(hipHostMalloc((void **)&t->h_rows, 64, hipHostMallocDefault)); t->h_rows[0] = 0; }
+        if (!t->h_rows) { CAFE_HIP_CHECK(hipHostMalloc((void **)&t->h_rows, 4 * kListRegions, hipHostMallocDefault)); memset(t->h_rows, 0, 4 * kListRegions); }
         if (!t->ev_rows) CAFE_HIP_CHECK(hipEventCreateWithFlags(&t->ev_rows, hipEventDisableTiming));
         if (!t->rows_pending) {
-            CAFE_HIP_CHECK(hipMemcpyAsync(t->h_rows, ecount, 4, hipMemcpyDeviceToHost, st));
+            CAFE_HIP_CHECK(hipMemcpyAsync(t->h_rows, ecount, 4 * kListRegions, hipMemcpyDeviceToHost, st));
             CAFE_HIP_CHECK(hipEventRecord(t->ev_rows, st));
             t->rows_pending = 1;
         }
@@ -1320,7 +1323,8 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         static const int apply_nt = getenv("CAFE_APPLY_NT") ? atoi(getenv("CAFE_APPLY_NT")) : 2;
         if (t->timing) { (void)hipEventRecord(t->ev_t[4][0], st); t->ev_epoch[4] = t->bwd_epoch; }
 #define CAFE_APPLY(L, V)                                                                                                 \
-    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, t->dim, lr, skip_rej, skip_seq, apply_nt, (uint32_t)total)
+    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, t->dim, lr, skip_rej, skip_seq, apply_nt, rcap, \
+                       d_fields, t->d_w_hot, t->d_w_cold, t->d_cold_base, t->hotn, batch)
         if (vpl == 1) {
             switch (lpg) {
                 case 1: CAFE_APPLY(1, 1); break;
@@ -1456,7 +1460,10 @@ static int step_common(cafe_sketch_t *s, cafe_tables_t *t, const StepArgs &a, ca
         const bool split = side != st && want_split_update(s, t, total);
         s->split_active = split ? 1 : 0;
         uint32_t rows_seen = 0;
-        if (t->rows_pending && hipEventQuery(t->ev_rows) == hipSuccess) { rows_seen = t->h_rows[0]; t->rows_pending = 0; }
+        if (t->rows_pending && hipEventQuery(t->ev_rows) == hipSuccess) {
+            for (int k = 0; k < kListRegions; ++k) rows_seen += t->h_rows[k];
+            t->rows_pending = 0;
+        }
         if (split && s->opt_split_update != 2 && (double)rows_seen > 0.4 * total) {
             t->split_pause = 256;            // (this step still runs split: the gather has queued its partition passes)
         } else if (!split && t->split_pause > 0) {
