@@ -1136,7 +1136,13 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
         if constexpr (EMIT) {
             if (tid == 0) s_lbase = region * rcap + claim;
             __syncthreads();
-            if (tid < (int)s_all) list[s_lbase + tid] = lent[tid];
+            if (tid < (int)s_all) {
+                // the row's address is worked out here, one entry per lane at the tile's end (inside the walk above it cost
+                // three dependent loads per row), so the row updates start from it
+                const uint4 en = lent[tid];
+                const unsigned long long a = (unsigned long long)row_ptr(en.x, en.y, fields, w_hot, w_cold, cold_base, hotn, batch, dim);
+                list[s_lbase + tid] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), en.z, en.w);
+            }
         }
     }
     __syncthreads();
@@ -1144,17 +1150,14 @@ __global__ void __launch_bounds__(256) k_bwd_segments(const uint32_t *__restrict
     BWD_STAMP(2);
 }
 
-// Second half of the split update: list entry = {row key, a lookup of the row, 1 plain / 2 atomic, where the row's sum is};
+// Second half of the split update: list entry = {address of the table row (two words), 1 plain / 2 atomic, where the row's sum is};
 // W[row] -= lr * sums[entry] (plain read-modify-write;
 // float atomics for the rows of a partition that was walked in several tiles, as in the one-kernel form).  A lane group
 // per row, grid-stride over the *ecount rows of the list.
 template <int LPG, int VPL>
 __global__ void __launch_bounds__(256) k_bwd_apply(const uint32_t *__restrict__ ecount, const uint4 *__restrict__ list,
                                                    const float4 *__restrict__ sums, int dim, float lr,
-                                                   const uint32_t *__restrict__ skip_rej, uint32_t skip_seq, int nt, uint32_t cap,
-                                                   const int32_t *__restrict__ fields, float *__restrict__ w_hot,
-                                                   float *const *__restrict__ w_cold, const int64_t *__restrict__ cold_base, int hotn,
-                                                   int batch) {
+                                                   const uint32_t *__restrict__ skip_rej, uint32_t skip_seq, int nt, uint32_t cap) {
     CAFE_KWIN(7);
     constexpr int G = 256 / LPG;
     const int lig = threadIdx.x % LPG, grp = threadIdx.x / LPG;
@@ -1178,7 +1181,7 @@ __global__ void __launch_bounds__(256) k_bwd_apply(const uint32_t *__restrict__ 
 #pragma unroll
         for (int b = kListRegions / 2; b > 0; b >>= 1) r += (pre[r + b] <= i) ? b : 0;
         const uint4 en = list[(size_t)r * cap + (i - pre[r])];
-        float *row = row_ptr(en.x, en.y, fields, w_hot, w_cold, cold_base, hotn, batch, dim);
+        float *row = reinterpret_cast<float *>(((unsigned long long)en.y << 32) | en.x);
         float4 sm[VPL], w[VPL];
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
@@ -1323,8 +1326,7 @@ static int backward_common(cafe_tables_t *t, const int32_t *d_fields, const int3
         static const int apply_nt = getenv("CAFE_APPLY_NT") ? atoi(getenv("CAFE_APPLY_NT")) : 2;
         if (t->timing) { (void)hipEventRecord(t->ev_t[4][0], st); t->ev_epoch[4] = t->bwd_epoch; }
 #define CAFE_APPLY(L, V)                                                                                                 \
-    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, t->dim, lr, skip_rej, skip_seq, apply_nt, rcap, \
-                       d_fields, t->d_w_hot, t->d_w_cold, t->d_cold_base, t->hotn, batch)
+    hipLaunchKernelGGL((k_bwd_apply<L, V>), dim3(agrid), dim3(256), 0, st, ecount, elist, sums, t->dim, lr, skip_rej, skip_seq, apply_nt, rcap)
         if (vpl == 1) {
             switch (lpg) {
                 case 1: CAFE_APPLY(1, 1); break;
