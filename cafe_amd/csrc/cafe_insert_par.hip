@@ -2008,28 +2008,31 @@ __global__ void __launch_bounds__(kThreads) k_finish(
     CAFE_STAMP(1, 0);
     // the scores as every owner formed them, for the caller (sk_embedding_bag.py:189): written whatever the verdict, but
     // AFTER this workgroup has published its totals -- the workgroups behind it wait for those, not for the scores
-    auto write_scores = [&]() {
-        if (!scores_out) return;
-        field_sums(g, sc, fsum);
-        __syncthreads();
-        const ScoreSrc ss = score_src(g, sc, fsum);
-#pragma unroll
-        for (int j = 0; j < kFinI; ++j) {
-            const int i = base + j * kThreads + tid;
-            if (i < g.n) scores_out[i] = ss.at((uint32_t)i);
-        }
-    };
-    CAFE_STAMP(1, 1);
-    const bool live = !ctl->overflow && ctl->final_round != 0;
-    if (!live) { write_scores(); return; }             // uniform; k_commit decides what happens to the batch
-    if (tid == 0) s_cross = 0;
+    // (what the scores need from memory -- the raw values, the fields' partial sums -- is requested with the kernel's first
+    // loads: between a workgroup's totals and its ranks only arithmetic and the stores are left)
     uint8_t mm[kFinI], om[kFinI], ol[kFinI];
+    float sv[kFinI];
 #pragma unroll
     for (int j = 0; j < kFinI; ++j) {
         const int i = base + j * kThreads + tid;
         const bool in = i < g.n;
         mm[j] = in ? miss[i] : 0; om[j] = in ? outm[i] : 0; ol[j] = in ? outl[i] : 0;
+        sv[j] = (scores_out && in && sc.vals) ? sc.vals[(size_t)i * (size_t)sc.vstride] : 1.0f;
     }
+    const bool live = !ctl->overflow && ctl->final_round != 0;
+    if (scores_out) field_sums(g, sc, fsum);
+    auto write_scores = [&]() {
+        if (!scores_out) return;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kFinI; ++j) {
+            const int i = base + j * kThreads + tid;
+            if (i < g.n) scores_out[i] = sc.psum ? sv[j] * (float)g.sseg / fsum[(uint32_t)i / (uint32_t)g.sseg] : sv[j];      // cafe_core.h::ScoreSrc::at
+        }
+    };
+    CAFE_STAMP(1, 1);
+    if (!live) { write_scores(); return; }             // uniform; k_commit decides what happens to the batch
+    if (tid == 0) s_cross = 0;
     EvRes er[kFinI];
 #pragma unroll
     for (int j = 0; j < kFinI; ++j) {
